@@ -1,0 +1,313 @@
+"""Seeded synthetic weights and inputs for the VIMA policy hot path.
+
+No checkpoints or datasets exist offline, so parity and
+benchmarks are defined on *shared seeded random weights + identical synthetic tensors*.
+This module is the single source of both:
+
+  * `make_state_dict(cfg, seed)`  -> dict with exactly the reference's state_dict keys and
+    shapes (`vima/__init__.py:11-14` loads it with strict=True).
+    Scales follow the reference constructors (0.02-normal GPT weights, width**-0.5 ViT
+    parameters, orthogonal-gain MLPs with the 0.01-gain action-head output layer,
+    T5 "factor 1.0" scales) but biases / LayerNorm affine terms are made non-trivial so
+    that every term of the arithmetic is exercised by the parity tests.
+  * `make_prompt(...)`, `make_obs(...)`, `make_actions(...)` -> inputs with the value
+    distributions of SURVEY.md section 8(d).
+
+Everything is generated on the CPU with an explicit `torch.Generator`, so the same
+(cfg, seed) gives bit-identical tensors here and on the GPU box.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, asdict
+
+import torch
+
+VIEWS = ("front", "top")  # sorted(["front", "top"]) -- obj_encoder.py:31
+ACTION_KEYS = ("pose0_position", "pose0_rotation", "pose1_position", "pose1_rotation")
+ACTION_DIMS = {  # vima_policy.py:82-87
+    "pose0_position": [50, 100],
+    "pose0_rotation": [50, 50, 50, 50],
+    "pose1_position": [50, 100],
+    "pose1_rotation": [50, 50, 50, 50],
+}
+N_LOGITS = 700
+T5_VOCAB = 32128
+VIT_WIDTH = 768
+VIT_LAYERS = 4
+VIT_HEADS = 24
+T5_LAYERS = 12
+T5_HEADS = 12
+T5_DKV = 64
+T5_DFF = 3072
+T5_BUCKETS = 32
+T5_MAXDIST = 128
+
+
+@dataclass(frozen=True)
+class PolicyConfig:
+    embed_dim: int
+    xf_n_layers: int
+    sattn_n_heads: int
+    xattn_n_heads: int
+    xattn_n_positions: int = 256  # reference hard-codes 256 (vima_policy.py:30)
+    n_positions: int = 512        # xattn_gpt.py:18
+
+    def ctor_kwargs(self):
+        return dict(embed_dim=self.embed_dim, xf_n_layers=self.xf_n_layers,
+                    sattn_n_heads=self.sattn_n_heads, xattn_n_heads=self.xattn_n_heads)
+
+    def asdict(self):
+        return asdict(self)
+
+
+# model-size ladder
+CONFIGS = {
+    "2M": PolicyConfig(256, 1, 8, 8),
+    "4M": PolicyConfig(256, 2, 8, 8),
+    "9M": PolicyConfig(320, 3, 10, 10),
+    "20M": PolicyConfig(384, 4, 12, 12),
+    "43M": PolicyConfig(512, 5, 16, 16),
+    "92M": PolicyConfig(640, 7, 20, 20),
+    "200M": PolicyConfig(768, 11, 24, 24),
+}
+
+
+def config(name: str, xattn_n_positions: int = 256) -> PolicyConfig:
+    c = CONFIGS[name]
+    return PolicyConfig(c.embed_dim, c.xf_n_layers, c.sattn_n_heads, c.xattn_n_heads,
+                        xattn_n_positions=xattn_n_positions)
+
+
+class _Init:
+    def __init__(self, seed: int):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(seed)
+        self.sd: dict[str, torch.Tensor] = {}
+
+    def normal(self, key, shape, std, mean=0.0):
+        t = torch.empty(*shape, dtype=torch.float32).normal_(mean, std, generator=self.g)
+        self.sd[key] = t
+        return t
+
+    def const(self, key, t):
+        self.sd[key] = t
+        return t
+
+    def ln(self, prefix, dim, bias=True):
+        self.normal(prefix + ".weight", (dim,), 0.1, 1.0)
+        if bias:
+            self.normal(prefix + ".bias", (dim,), 0.05)
+
+    def linear(self, prefix, out_f, in_f, std, bias=True, bias_std=0.02):
+        self.normal(prefix + ".weight", (out_f, in_f), std)
+        if bias:
+            self.normal(prefix + ".bias", (out_f,), bias_std)
+
+    def mlp(self, prefix, dims, last_gain=None):
+        """build_mlp layout: Sequential indices 0,3,6,... (nn/utils.py:84-91). Orthogonal-like scale."""
+        gain = math.sqrt(2.0)
+        for i in range(len(dims) - 1):
+            in_f, out_f = dims[i], dims[i + 1]
+            g = gain
+            if last_gain is not None and i == len(dims) - 2:
+                g = last_gain
+            self.linear(f"{prefix}.{3 * i}", out_f, in_f, g / math.sqrt(max(in_f, out_f)))
+
+
+def make_state_dict(cfg: PolicyConfig, seed: int = 0) -> dict[str, torch.Tensor]:
+    """State dict with the reference `VIMAPolicy` key layout."""
+    E, N = cfg.embed_dim, cfg.xf_n_layers
+    I = _Init(seed)
+    # ---- xattn_gpt (xattn_gpt.py:45-68, components.py) ----
+    p = "xattn_gpt."
+    I.const(p + "position_ids", torch.arange(cfg.n_positions))
+    I.const(p + "xattn_position_ids", torch.arange(cfg.xattn_n_positions))
+    I.normal(p + "positions_embed.weight", (cfg.n_positions, E), 0.02)
+    I.normal(p + "xattn_positions_embed.weight", (cfg.xattn_n_positions, E), 0.02)
+    tril = torch.tril(torch.ones(cfg.n_positions, cfg.n_positions)).view(1, 1, cfg.n_positions, cfg.n_positions)
+    for i in range(N):
+        h = f"{p}h.{i}."
+        I.const(h + "attn.bias", tril)
+        w = I.normal(h + "attn.c_attn.weight", (E, 3 * E), 0.02)   # Conv1D: [in, out]
+        w[:, : 2 * E] *= 3.0                                        # peaked q.k logits
+        I.normal(h + "attn.c_attn.bias", (3 * E,), 0.02)
+        I.normal(h + "attn.c_proj.weight", (E, E), 0.02)
+        I.normal(h + "attn.c_proj.bias", (E,), 0.02)
+        I.ln(h + "ln_1", E)
+        I.normal(h + "mlp.c_fc.weight", (E, 4 * E), 0.02)
+        I.normal(h + "mlp.c_fc.bias", (4 * E,), 0.02)
+        I.normal(h + "mlp.c_proj.weight", (4 * E, E), 0.02)
+        I.normal(h + "mlp.c_proj.bias", (E,), 0.02)
+        I.normal(h + "mlp.gated_layer.weight", (4 * E, E), 0.02)
+        I.ln(h + "ln_2", E)
+    for i in range(N):
+        x = f"{p}xattns.{i}."
+        I.const(x + "kv_position_ids", torch.arange(cfg.xattn_n_positions))
+        I.ln(x + "layernorm", E)
+        I.normal(x + "query.weight", (E, E), 0.06)
+        kv = I.normal(x + "key_value.weight", (2 * E, E), 0.02)
+        kv[:E] *= 3.0
+        I.normal(x + "attention_out.weight", (E, E), 0.02)
+        I.ln(x + "ln", E)
+        I.normal(x + "linear1.weight", (4 * E, E), 0.02)
+        I.normal(x + "linear2.weight", (E, 4 * E), 0.02)
+        I.normal(x + "gated_layer.weight", (4 * E, E), 0.02)
+    # ---- obj_encoder (obj_encoder.py:15-64, vit.py:137-169) ----
+    v = "obj_encoder.cropped_img_encoder.vit."
+    W = VIT_WIDTH
+    sc = W ** -0.5
+    I.normal(v + "cls_token", (W,), sc)
+    I.normal(v + "pos_embed", (5, W), sc)
+    I.normal(v + "projection", (W, W), sc)
+    I.normal(v + "conv1.weight", (W, 3, 16, 16), 0.02)
+    I.ln(v + "ln_pre", W)
+    for j in range(VIT_LAYERS):
+        b = f"{v}blocks.{j}."
+        w = I.normal(b + "attn.in_proj_weight", (3 * W, W), 0.0255)
+        w[: 2 * W] *= 2.5
+        I.normal(b + "attn.in_proj_bias", (3 * W,), 0.02)
+        I.linear(b + "attn.out_proj", W, W, 0.0209)
+        I.ln(b + "ln_1", W)
+        I.linear(b + "mlp.c_fc", 4 * W, W, 0.0208)
+        I.linear(b + "mlp.c_proj", W, 4 * W, 0.0104)
+        I.ln(b + "ln_2", W)
+    I.ln(v + "ln_post", W)
+    for view in VIEWS:
+        I.mlp(f"obj_encoder.bbox_mlp.{view}", [4, 768, 768, 768])
+    for view in VIEWS:
+        I.linear(f"obj_encoder.pre_transformer_layer.{view}", E, 2 * W, (2 * W) ** -0.5 * 0.58)
+    # ---- obs fusion (vima_policy.py:47-49) ----
+    I.normal("end_effector_encoder.weight", (2, 2), 0.7)
+    I.linear("obs_fusion_layer", E, E + 2, (E + 2) ** -0.5 * 0.58)
+    # ---- action encoder (vima_policy.py:51-80, action_embd.py) ----
+    for k in ACTION_KEYS:
+        in_dim = 2 if k.endswith("position") else 4
+        I.mlp(f"action_encoder._embed_dict.{k}._layer", [in_dim, 256, 256])
+    I.linear("action_encoder._post_layer", E, 1024, 1024 ** -0.5 * 0.58)
+    # ---- action decoder (action_decoder.py:128-166) ----
+    for k in ACTION_KEYS:
+        for j, bins in enumerate(ACTION_DIMS[k]):
+            I.mlp(f"action_decoder._decoders.{k}.mlps.{j}", [E, 512, 512, bins], last_gain=0.01)
+    # ---- word embedding + T5 encoder (word_embd.py, prompt_encoder.py) ----
+    I.normal("prompt_embedding._embed_layer.weight", (T5_VOCAB, 768), 1.0)
+    t5 = "t5_prompt_encoder.t5."
+    dead = torch.zeros(T5_VOCAB, 768)  # never read at inference (inputs_embeds path); strict load needs the keys
+    I.const(t5 + "shared.weight", dead)
+    I.const(t5 + "encoder.embed_tokens.weight", dead)
+    d_model, inner = 768, T5_HEADS * T5_DKV
+    for l in range(T5_LAYERS):
+        a = f"{t5}encoder.block.{l}.layer.0."
+        I.normal(a + "SelfAttention.q.weight", (inner, d_model), (d_model * T5_DKV) ** -0.5 * 2.0)
+        I.normal(a + "SelfAttention.k.weight", (inner, d_model), d_model ** -0.5 * 1.5)
+        I.normal(a + "SelfAttention.v.weight", (inner, d_model), d_model ** -0.5)
+        I.normal(a + "SelfAttention.o.weight", (d_model, inner), inner ** -0.5)
+        if l == 0:
+            I.normal(a + "SelfAttention.relative_attention_bias.weight", (T5_BUCKETS, T5_HEADS), 1.0)
+        I.normal(a + "layer_norm.weight", (d_model,), 0.1, 1.0)
+        f = f"{t5}encoder.block.{l}.layer.1."
+        I.normal(f + "DenseReluDense.wi.weight", (T5_DFF, d_model), d_model ** -0.5)
+        I.normal(f + "DenseReluDense.wo.weight", (d_model, T5_DFF), T5_DFF ** -0.5)
+        I.normal(f + "layer_norm.weight", (d_model,), 0.1, 1.0)
+    I.normal(t5 + "encoder.final_layer_norm.weight", (d_model,), 0.1, 1.0)
+    if E != 768:
+        I.normal("t5_prompt_encoder_post_layer.weight", (E, 768), 768 ** -0.5)
+    I.mlp("prompt_obj_post_layer", [E, 768, 768, 768])
+    return I.sd
+
+
+def state_dict_checksum(sd) -> float:
+    """Cheap fingerprint used by the golden fixtures to detect RNG drift."""
+    tot = 0.0
+    for k in sorted(sd):
+        t = sd[k]
+        if t.dtype.is_floating_point and t.numel() < 5_000_000:
+            tot += float(t.double().abs().sum())
+    return tot
+
+
+# --------------------------------------------------------------------------------------
+# inputs
+# --------------------------------------------------------------------------------------
+class MapDict(dict):
+    """Nested dict exposing `.map_structure(func=)` like the reference's DataDict
+    (vima/utils.py:495-508); `forward_obs_token` calls it (vima_policy.py:246)."""
+
+    def map_structure(self, func):
+        def rec(x):
+            if isinstance(x, dict):
+                return MapDict({k: rec(v) for k, v in x.items()})
+            return func(x)
+        return rec(self)
+
+    def to(self, device):
+        return self.map_structure(lambda x: x.to(device))
+
+
+def _objects(g, lead, q_per_view, mask_frac=0.1):
+    """crops uint8 U{0..255}; bbox (xc,yc,h,w) ranges of SURVEY 8(d); masks ~mask_frac False,
+    never the first object of the front view (else position id -1, vima_policy.py:145)."""
+    crops, bbox, mask = {}, {}, {}
+    for vi, view in enumerate(VIEWS):
+        crops[view] = torch.randint(0, 256, (*lead, q_per_view, 3, 32, 32), generator=g, dtype=torch.int64).to(torch.uint8)
+        xc = torch.randint(0, 256, (*lead, q_per_view, 1), generator=g)
+        yc = torch.randint(0, 128, (*lead, q_per_view, 1), generator=g)
+        hh = torch.randint(1, 128, (*lead, q_per_view, 1), generator=g)
+        ww = torch.randint(1, 256, (*lead, q_per_view, 1), generator=g)
+        bbox[view] = torch.cat([xc, yc, hh, ww], dim=-1)
+        m = torch.rand(*lead, q_per_view, generator=g) >= mask_frac
+        if vi == 0:
+            m[..., 0] = True
+        mask[view] = m
+    return MapDict(cropped_img=MapDict(crops), bbox=MapDict(bbox), mask=MapDict(mask))
+
+
+def make_prompt(batch: int, layout: list[list[int]] | None = None, *, n_segments: int = 2,
+                words_per_segment: int = 4, q_per_view: int = 2, seed: int = 1234, mask_frac: float = 0.1):
+    """Returns the `prompts` triple consumed by `forward_prompt_assembly` (vima_policy.py:161-162):
+    (raw_prompts_token_type, word_batch, image_batch). Default layout: `n_segments` x
+    [words_per_segment words, 1 image -> 2*q_per_view object tokens]."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    if layout is None:
+        layout = [([0] * words_per_segment + [1]) * n_segments for _ in range(batch)]
+    assert len(layout) == batch
+    n_words = sum(t == 0 for p in layout for t in p)
+    n_img = sum(t == 1 for p in layout for t in p)
+    word_batch = torch.randint(0, 32100, (n_words,), generator=g)
+    image_batch = _objects(g, (max(n_img, 0),), q_per_view, mask_frac)
+    return layout, word_batch, image_batch
+
+
+def prompt_len(layout, q_per_view):
+    return max(sum(1 if t == 0 else 2 * q_per_view for t in p) for p in layout)
+
+
+def make_obs(steps: int, batch: int, q_per_view: int, seed: int = 4321, mask_frac: float = 0.1):
+    """obs dict consumed by `forward_obs_token` (vima_policy.py:242-259)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    objects = _objects(g, (steps, batch), q_per_view, mask_frac)
+    ee = torch.randint(0, 2, (steps, batch), generator=g)
+    return {"objects": objects, "ee": ee}
+
+
+def make_actions(steps: int, batch: int, seed: int = 777):
+    """Discrete past actions (int64 bin indices) as produced by `MultiCategorical.mode()`."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    out = {}
+    for k in ACTION_KEYS:
+        cols = [torch.randint(0, b, (steps, batch, 1), generator=g) for b in ACTION_DIMS[k]]
+        out[k] = torch.cat(cols, dim=-1)
+    return out
+
+
+def to_device(x, device):
+    if isinstance(x, dict):
+        return type(x)({k: to_device(v, device) for k, v in x.items()})
+    if isinstance(x, (list, tuple)):
+        return type(x)(to_device(v, device) for v in x)
+    if torch.is_tensor(x):
+        return x.to(device)
+    return x
