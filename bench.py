@@ -1,0 +1,182 @@
+"""bench.py -- policy-forward steps/sec of the MI355X-native VIMA policy (BASELINE.json metric).
+
+One step = one COLD batched policy evaluation: raw uint8 crops / bboxes / word ids ->
+forward_prompt_assembly (object ViT + T5) -> forward_obs_token (ViT) -> forward (XAttnGPT) -> action head -> [B,700]
+logits, on synthetic inputs already resident in HBM. Default workload = BASELINE.json configs[2]:
+VIMA-200M, batch 256 per GPU, 512-token prompt (32 x [8 words + 1 image -> 8 object tokens]), 8 object tokens/obs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+
+Multi-GPU = data parallel, weak scaling: every rank evaluates its own batch of 256 with a full weight replica and the
+only collective is one all-gather of the [256,700] logits per step (vima_amd/parallel.py).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X (guides/MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3
+
+
+def flops_per_sample(E, N, Lp, n_prompt_obj, Q, T):
+    """Algorithmic FLOPs (2 per MAC) of one sample, formulas of SURVEY.md section 8(d)."""
+    vit = 2 * 4 * 768 * 768 + 4 * (2 * 5 * 768 * 2304 + 4 * 25 * 768 + 2 * 5 * 768 ** 2 + 2 * (2 * 5 * 768 * 3072)) + 2 * 768 ** 2
+    obj = vit + 2 * (4 * 768 + 768 ** 2 + 768 ** 2) + 2 * 1536 * E
+    obs = obj + 2 * (E + 2) * E
+    pobj = obj + 2 * (E * 768 + 768 ** 2 + 768 ** 2)
+    t5 = 12 * (24 * Lp * 768 ** 2 + 4 * Lp ** 2 * 768) + (2 * Lp * 768 * E if E != 768 else 0)
+    Lq = T * (Q + 1) - 1
+    xgpt = N * (60 * Lq * E ** 2 + 4 * Lp * E ** 2 + 4 * Lq * Lp * E + 4 * Lq ** 2 * E)
+    head = 12 * 2 * (E * 512 + 512 ** 2) + 2 * 512 * 700
+    prompt = n_prompt_obj * pobj + t5
+    step = T * Q * obs + xgpt + head
+    return prompt + step, step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU per step")
+    ap.add_argument("--model", default="200M")
+    ap.add_argument("--prompt-len", type=int, default=512)
+    ap.add_argument("--qv", type=int, default=4, help="objects per view (Q = 2*qv object tokens per observation)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vima_amd import synthetic as syn, parallel
+    from vima_amd.policy import VIMAPolicy
+
+    Q = 2 * args.qv
+    seg_len = 8 + Q                                  # 8 words + 1 image (Q object tokens) per segment
+    assert args.prompt_len % seg_len == 0, "prompt length must be a multiple of 8 + Q"
+    n_seg = args.prompt_len // seg_len
+    cfg = syn.config(args.model, xattn_n_positions=max(256, args.prompt_len))
+    sd = syn.make_state_dict(cfg, 0)                 # seeded random weights (no checkpoints offline)
+    pol = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision=args.precision, device=dev)
+    pol.load_state_dict(sd, strict=True)
+    B = args.batch
+    prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=8, q_per_view=args.qv, seed=1236 + rank), dev)
+    obs = syn.to_device(syn.make_obs(1, B, args.qv, seed=1336 + rank), dev)
+
+    def step():
+        ptok, pmask = pol.forward_prompt_assembly(prompts)
+        otok, omask = pol.forward_obs_token(obs)
+        pred = pol.forward(otok, omask, None, ptok, pmask)
+        logits = pol.action_logits(pred[-1])
+        return parallel.all_gather_logits(logits, global_batch=B * world) if world > 1 else logits
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape == (B * world, 700) and bool(torch.isfinite(out).all())
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- per-class kernel time (HIP events on the launch stream), same workload, outside the timed region
+    pol.prof_enable(True)
+    step()
+    torch.cuda.synchronize(dev)
+    prof = pol.prof_read()
+    pol.prof_enable(False)
+
+    cold, warm = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, 1)
+    peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
+    gemm = prof["gemm"]
+    gemm_tflops = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "kernel": "vima::gemm_kernel (bf16 mfma_f32_32x32x16)" if args.precision == "bf16" else "vima::gemm_kernel (fp32 mfma)",
+        "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
+        "traffic": None,
+        "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / max(gemm["launches"], 1), 2),
+        "gemm_ms_per_step": round(gemm["ms"], 3), "attention_ms_per_step": round(prof["attention"]["ms"], 3),
+        "other_ms_per_step": round(prof["other"]["ms"], 3),
+        "whole_step_tflops": round(B * cold / (ms_per_step * 1e-3) / 1e12, 2),
+        "whole_step_frac": round(B * cold / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.vima_oracle import OraclePolicy
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        orc = OraclePolicy(sd, **cfg.ctor_kwargs())
+        cb = args.cpu_batch
+        p_cpu = syn.make_prompt(cb, n_segments=n_seg, words_per_segment=8, q_per_view=args.qv, seed=1236)
+        o_cpu = syn.make_obs(1, cb, args.qv, seed=1336)
+        with torch.no_grad():
+            orc.cold_step(p_cpu, o_cpu)                         # warm-up
+            t1 = time.perf_counter()
+            it = 0
+            while it < 3 and (time.perf_counter() - t1) < 25.0:
+                orc.cold_step(p_cpu, o_cpu)
+                it += 1
+            cdt = (time.perf_counter() - t1) / max(it, 1)
+        samples_per_s = cb / cdt
+        cpu_baseline = {"value": round(samples_per_s / B, 6), "unit": "steps/s", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"oracle (torch fp32 restatement of the reference CPU path), same workload at batch {cb} "
+                                  f"({it} timed passes, {cdt:.2f} s each = {samples_per_s:.2f} samples/s), scaled to batch-{B} steps",
+                        "host_cpu_count": ncores}
+
+    if rank == 0:
+        line = {
+            "metric": "policy-forward steps/sec, VIMA-200M, 512-token prompt, batch 256",
+            "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"VIMA-{args.model} COLD policy forward (prompt assembly ViT+T5, obs ViT, XAttnGPT, action head) "
+                                   f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [8 words + 1 image]), {Q} object tokens/obs, T=1",
+                       "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}",
+                       "samples_per_s": round(world * B * args.steps / dt, 1),
+                       "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

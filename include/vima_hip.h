@@ -1,0 +1,139 @@
+/* vima_hip.h -- C ABI of the MI355X-native (gfx950) VIMA policy forward pass.
+ *
+ * The reference (vimalabs/VIMA) is pure Python: it has no FFI of its own, its seam is the method surface of
+ * `VIMAPolicy` (vima/policy/vima_policy.py:11-322) and the checkpoint contract of `create_policy_from_ckpt`
+ * (vima/__init__.py:7-16). This library is what a binding for that seam binds to: one opaque handle per
+ * (model, device) and one entry point per policy method. All tensors are plain device pointers owned by the
+ * caller (row-major, contiguous unless strides are given); the library never frees caller memory, launches on
+ * the caller's hipStream_t and keeps its own workspace. Every function returns 0 on success, otherwise an error
+ * code whose text is available from vima_last_error(). The Python host side (vima_amd/policy.py) loads this
+ * library with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions: f32 = float, i64 = int64_t, u8 = uint8_t (also used for torch.bool). Views are ordered
+ * sorted(["front","top"]) = {front, top} (obj_encoder.py:31). E = embed_dim.
+ */
+#ifndef VIMA_HIP_H
+#define VIMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct VimaHandle VimaHandle;
+typedef void* vima_stream_t; /* hipStream_t */
+
+enum { VIMA_PRECISION_FP32 = 0, VIMA_PRECISION_BF16 = 1 };
+
+/* Constructor arguments of VIMAPolicy (vima_policy.py:12-19) plus the two table sizes the reference hard-codes
+ * (xattn_n_positions=256 at vima_policy.py:30, n_positions=512 at xattn_gpt.py:18). */
+typedef struct VimaConfig {
+  int32_t embed_dim;
+  int32_t xf_n_layers;
+  int32_t sattn_n_heads;
+  int32_t xattn_n_heads;
+  int32_t xattn_n_positions;
+  int32_t n_positions;
+  int32_t precision; /* VIMA_PRECISION_*: operand type of the matrix-core GEMMs / attention (accumulation, residual
+                        stream, LayerNorm and softmax statistics are always fp32) */
+} VimaConfig;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+/* replaces VIMAPolicy.__init__ (vima_policy.py:12-114) */
+int vima_create(const VimaConfig* cfg, int device, VimaHandle** out);
+void vima_destroy(VimaHandle* h);
+const char* vima_last_error(void);
+int vima_abi_version(void);
+
+/* ---- weights: the reference checkpoint contract -------------------------------------------------------------- */
+/* replaces nn.Module.load_state_dict(strict=True) as used by create_policy_from_ckpt (vima/__init__.py:11-14).
+ * `name` is the reference state_dict key, `data` a HOST fp32 array in the reference's own
+ * layout (HF Conv1D weights are [in,out], nn.Linear [out,in] -- the library repacks). Integer buffers of the
+ * reference state_dict (position_ids, attn.bias, ...) carry no information and are not passed. */
+int vima_set_param(VimaHandle* h, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Packs / converts / uploads; fails (strict) listing any key that was never set or has the wrong shape. */
+int vima_finalize_params(VimaHandle* h);
+/* Host-only (no GPU needed): writes the NUL-separated list of state_dict keys vima_finalize_params requires for
+ * this config into buf (when it fits) and returns the number of bytes needed. */
+int64_t vima_required_params(const VimaConfig* cfg, char* buf, int64_t buflen);
+
+/* ---- policy methods ------------------------------------------------------------------------------------------ */
+/* ObjEncoder.forward (obj_encoder.py:66-95): crops[v] u8 [n,Qv,3,32,32], bbox[v] i64 [n,Qv,4] (xc,yc,h,w px)
+ * -> out f32 [n, 2*Qv, E] with the object axis ordered [front objs..., top objs...]. */
+int vima_obj_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2], int n, int qv,
+                    float* out, vima_stream_t stream);
+
+/* VIMAPolicy.forward_obs_token (vima_policy.py:242-259): leading dims [T,B] flattened to n = T*B.
+ * mask[v] u8 [n,Qv]; ee i64 [n] in {0,1} -> out_tokens f32 [n, 2*Qv, E], out_mask u8 [n, 2*Qv]. */
+int vima_obs_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2],
+                    const uint8_t* const mask[2], const int64_t* ee, int n, int qv, float* out_tokens,
+                    uint8_t* out_mask, vima_stream_t stream);
+
+/* VIMAPolicy.forward_prompt_assembly (vima_policy.py:161-240). The python double loop over token types is replaced
+ * by an index array built on the host: tok_src i32 [B*Lp] (device), one code per (b, l):
+ *     >= 0 : index into word_ids            (word token, mask True)
+ *     -1   : padding                        (zeros, mask False)
+ *     <= -2: object token -(code+2) = img*2*Qv + q of the encoded prompt images (mask = object mask)
+ * word_ids i64 [n_words]; crops/bbox/mask as above with n = n_img.
+ * -> out_tokens f32 [B, Lp, E] (batch-first; the reference returns the [Lp,B,E] transposed view of it),
+ *    out_mask u8 [B, Lp]. */
+int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, const uint8_t* const crops[2],
+                       const int64_t* const bbox[2], const uint8_t* const mask[2], int n_img, int qv,
+                       const int32_t* tok_src, int B, int Lp, float* out_tokens, uint8_t* out_mask,
+                       vima_stream_t stream);
+
+/* T5PromptEncoder.forward (prompt_encoder.py:30-58) on already assembled embeddings x f32 [B,L,768], mask u8 [B,L]
+ * -> out f32 [B,L,768] (before t5_prompt_encoder_post_layer). Exposed for operator-level parity tests. */
+int vima_t5_encode(VimaHandle* h, const float* x, const uint8_t* mask, int B, int L, float* out,
+                   vima_stream_t stream);
+
+/* VIMAPolicy.forward (vima_policy.py:116-159) -> XAttnGPT.forward (xattn_gpt.py:73-139).
+ * obs_tok f32 [T,B,Q,E], obs_mask u8 [T,B,Q], act_tok f32 [L_act,B,E] or NULL (L_act in {T-1, T}),
+ * prompt f32 element (b,l,e) at prompt[b*stride_b + l*stride_l + e] (so both the [B,Lp,E] buffer and the reference's
+ * sequence-first [Lp,B,E] layout can be passed), prompt_mask u8 [B,Lp] -> out f32 [T,B,E] (sequence-first). */
+int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B,
+                int Q, int L_act, const float* prompt, int64_t stride_b, int64_t stride_l,
+                const uint8_t* prompt_mask, int Lp, float* out, vima_stream_t stream);
+
+/* VIMAPolicy.forward_action_decoder (vima_policy.py:264-265 -> action_decoder.py:51-52,165-166): tokens f32 [R,E]
+ * -> raw logits f32 [R,700] = concat over keys (pose0_position, pose0_rotation, pose1_position, pose1_rotation) of
+ * the 12 MLP outputs; the MultiCategorical wrapper (dists.py) stays on the host side. */
+int vima_action_head(VimaHandle* h, const float* tokens, int R, float* out_logits, vima_stream_t stream);
+
+/* VIMAPolicy.forward_action_token (vima_policy.py:261-262 -> :301-322 -> action_embd.py:29-56): discrete bin
+ * indices i64, keys in sorted order: pose0_position [R,2], pose0_rotation [R,4], pose1_position [R,2],
+ * pose1_rotation [R,4] -> out f32 [R,E]. */
+int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int R, float* out, vima_stream_t stream);
+
+/* ---- operator-level entry points (parity tests / microbenchmarks) ---------------------------------------------- */
+/* out = epilogue(A[M,K] . W[N,K]^T) in the handle's precision; fp32 host-visible device buffers in/out, the
+ * operand conversion is done internally. act: 0 none, 1 relu, 2 gelu(erf), 3 quickgelu. bias/mul/res may be NULL. */
+int vima_op_linear(VimaHandle* h, const float* A, const float* W, const float* bias, const float* mul,
+                   const float* res, int M, int N, int K, int act, float* out, vima_stream_t stream);
+/* LayerNorm (rms=0) / T5 RMSNorm (rms=1) over rows of length E. */
+int vima_op_layernorm(VimaHandle* h, const float* x, const float* gamma, const float* beta, float eps, int rms,
+                      int rows, int E, float* out, vima_stream_t stream);
+/* attention on fp32 buffers q [B,Lq,H*D], k/v [B,Lk,H*D]; mode 0 T5 (relbias [H][2Lk-1]), 1 cross, 2 causal;
+ * impl 0 = exact generic kernel, 1 = MFMA flash kernel (bf16 precision only). */
+int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float* v, const uint8_t* kmask,
+                      const float* relbias, int B, int H, int Lq, int Lk, int D, float scale, int mode, int impl,
+                      float* out, vima_stream_t stream);
+/* host-only: HF T5 bidirectional relative-position bucket (32 buckets, max distance 128) of (key_pos - query_pos) */
+int vima_t5_bucket(int relative_position);
+
+/* ---- tuning / instrumentation ---------------------------------------------------------------------------------- */
+/* key in {"attn_impl" (0 generic, 1 mfma), "gemm_variant" (0 builtin LDS-DMA, 1 asm LDS-DMA), "vit_chunk" (crops)} */
+int vima_set_option(VimaHandle* h, const char* key, int64_t value);
+/* When enabled every kernel launch is bracketed by HIP events on the launch stream and attributed to a class:
+ * 0 = GEMM, 1 = attention, 2 = other. vima_prof_read synchronises and returns per class
+ * {milliseconds, launches, algorithmic FLOPs (2*M*N*K for GEMMs, 4*B*H*Lq*Lk*D for attention)}; then resets. */
+int vima_prof_enable(VimaHandle* h, int on);
+int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], double out_flops[3]);
+/* bytes currently held by the workspace arena */
+int64_t vima_workspace_bytes(VimaHandle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIMA_HIP_H */

@@ -1,0 +1,75 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol declared in include/vima_hip.h,
+its host-only helpers agree with the oracle, and it fails loudly (no CPU fallback) without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from vima_amd import _lib, synthetic as syn
+from oracle.vima_oracle import t5_relative_position_bucket
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "vima_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(vima_[a-z0-9_]+)\s*\(", src)) - {"vima_stream_t"}
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _header_functions()
+    assert declared, "no functions parsed from include/vima_hip.h"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vima_hip.h but not exported by libvima_hip.so"
+    assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
+    assert lib.vima_abi_version() == 1
+
+
+def test_t5_bucket_matches_oracle():
+    lib = _lib.load()
+    rel = torch.arange(-2100, 2101)
+    want = t5_relative_position_bucket(rel).tolist()
+    got = [lib.vima_t5_bucket(int(r)) for r in rel.tolist()]
+    assert got == want
+
+
+@pytest.mark.parametrize("name", ["2M", "20M", "200M"])
+def test_required_params_match_reference_key_layout(name):
+    """The keys the C library demands == the float keys of the reference state_dict layout
+    minus the buffers / dead tables that carry no information."""
+    from vima_amd.policy import VIMAPolicy
+    cfg = syn.config(name)
+    pol = VIMAPolicy(**cfg.ctor_kwargs())
+    req, ign = pol.expected_keys()
+    n = cfg.xf_n_layers
+    # count check against the analytic layout: per decoder layer 12 (block) + 10 (xattn) float tensors etc.
+    assert len(req) == len(set(req))
+    if name == "2M":
+        sd = syn.make_state_dict(cfg, 0)
+        assert set(req) | set(ign) == set(sd.keys())
+        assert not (set(req) & set(ign))
+    assert sum(k.startswith("xattn_gpt.h.") for k in req) == 13 * n
+    assert sum(k.startswith("xattn_gpt.xattns.") for k in req) == 10 * n
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    from vima_amd.policy import VIMAPolicy
+    cfg = syn.config("2M")
+    pol = VIMAPolicy(**cfg.ctor_kwargs())
+    with pytest.raises(RuntimeError):
+        pol.load_state_dict({}, strict=False)
+    h = ctypes.c_void_p()
+    c = _lib.VimaConfig(256, 1, 8, 8, 256, 512, 1)
+    assert _lib.load().vima_create(ctypes.byref(c), 0, ctypes.byref(h)) != 0
+    assert b"no HIP device" in _lib.load().vima_last_error()
+
+
+def test_bad_config_raises_value_error():
+    from vima_amd.policy import VIMAPolicy
+    with pytest.raises(ValueError):
+        VIMAPolicy(embed_dim=250, xf_n_layers=1, sattn_n_heads=8, xattn_n_heads=8)

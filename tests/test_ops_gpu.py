@@ -1,0 +1,126 @@
+"""Operator-level parity on a real MI355X: each hand-written HIP kernel against a plain PyTorch fp32 restatement of
+the same op (CPU). fp32 mode must agree to fp32 round-off; bf16 mode is compared with a reference that rounds the
+OPERANDS to bf16 the same way (products/accumulation fp32 on both sides)."""
+import math
+
+import pytest
+import torch
+
+from vima_amd import _lib
+from tests.gpu_common import bare_policy, bf, max_rel, ptr
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: lambda x: x, 1: torch.relu, 2: torch.nn.functional.gelu, 3: lambda x: x * torch.sigmoid(1.702 * x)}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (100, 50, 512), (8, 768, 768), (333, 700, 256), (1030, 2304, 768),
+                                   (130, 132, 1536), (1, 100, 512)])
+def test_linear_epilogues(prec, variant, M, N, K):
+    pol = bare_policy(prec)
+    pol.set_option("gemm_variant", variant)
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    for act, use_b, use_m, use_r in [(0, 0, 0, 0), (1, 1, 0, 0), (2, 1, 1, 0), (3, 1, 0, 1), (2, 0, 1, 1)]:
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * K ** -0.5
+        b = torch.randn(N, generator=g) if use_b else None
+        m = torch.randn(M, N, generator=g) if use_m else None
+        r = torch.randn(M, N, generator=g) if use_r else None
+        ref = (bf(A) @ bf(W).T) if prec == "bf16" else (A @ W.T)
+        if b is not None:
+            ref = ref + b
+        ref = ACTS[act](ref)
+        if m is not None:
+            ref = ref * (bf(m) if prec == "bf16" else m)
+        if r is not None:
+            ref = ref + r
+        d = [None if t is None else t.cuda() for t in (A, W, b, m, r)]
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, act,
+                                           ptr(out), pol._stream()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        assert max_rel(out, ref) < (2e-3 if prec == "bf16" else 2e-5), (act, use_b, use_m, use_r)
+
+
+def test_linear_transpose_detecting():
+    """A = I with an asymmetric W: output must equal W^T exactly (catches swapped C-layout / operand order)."""
+    pol = bare_policy("fp32")
+    n = 128
+    A = torch.eye(n)
+    W = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    out = torch.empty(n, n, device="cuda")
+    Ad, Wd = A.cuda(), W.cuda()
+    _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(Ad), ptr(Wd), None, None, None, n, n, n, 0, ptr(out), pol._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), W.T)
+
+
+@pytest.mark.parametrize("rows,E,rms", [(7, 256, 0), (1000, 768, 0), (513, 384, 1), (64, 1024, 0), (5, 320, 1)])
+def test_layernorm(rows, E, rms):
+    pol = bare_policy("fp32")
+    g = torch.Generator().manual_seed(rows + E)
+    x = torch.randn(rows, E, generator=g) * 3 + 0.5
+    ga, be = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    if rms:
+        ref = ga * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    else:
+        ref = torch.nn.functional.layer_norm(x, (E,), ga, be, 1e-5)
+    out = torch.empty(rows, E, device="cuda")
+    xd, gd, bd = x.cuda(), ga.cuda(), be.cuda()
+    _lib.check(pol._lib.vima_op_layernorm(pol._handle, ptr(xd), ptr(gd), None if rms else ptr(bd), 1e-6 if rms else 1e-5, rms,
+                                          rows, E, ptr(out), pol._stream()))
+    torch.cuda.synchronize()
+    assert max_rel(out, ref) < 1e-5
+
+
+def attn_ref(q, k, v, kmask, relbias, scale, mode):
+    """Literal restatement of the three score pipelines (prompt_encoder.py:769-801, components.py:184-207, :54-69)."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k)
+    fmin = torch.finfo(torch.float32).min
+    madd = (1.0 - kmask[:, None, None, :].float()) * fmin
+    if mode == 0:
+        idx = (torch.arange(Lk)[None, :] - torch.arange(Lq)[:, None]) + Lk - 1
+        s = s + (relbias[:, idx][None] + madd)
+    elif mode == 1:
+        s = s * scale + madd
+    else:
+        tri = torch.tril(torch.ones(Lq, Lk))
+        s = (s * scale) * tri + -1e4 * (1 - tri)
+        s = s + madd
+    return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, dim=-1), v)
+
+
+ATTN_CASES = [(0, 2, 12, 64, 64, 64), (0, 1, 12, 100, 100, 64), (1, 3, 8, 8, 40, 32), (1, 2, 24, 71, 300, 32),
+              (2, 2, 8, 9, 9, 32), (2, 3, 24, 71, 71, 32), (1, 2, 4, 5, 33, 64), (2, 1, 4, 40, 40, 64)]
+
+
+@pytest.mark.parametrize("prec,impl", [("fp32", 0), ("bf16", 0), ("bf16", 1)])
+@pytest.mark.parametrize("mode,B,H,Lq,Lk,D", ATTN_CASES)
+def test_attention(prec, impl, mode, B, H, Lq, Lk, D):
+    pol = bare_policy(prec)
+    g = torch.Generator().manual_seed(mode * 100 + Lq + Lk)
+    sc = 1.0 if mode else 0.4
+    q = torch.randn(B, Lq, H, D, generator=g) * sc
+    k = torch.randn(B, Lk, H, D, generator=g) * sc
+    v = torch.randn(B, Lk, H, D, generator=g)
+    kmask = torch.rand(B, Lk, generator=g) > 0.2
+    kmask[:, 0] = True
+    if B > 1 and mode == 1:
+        kmask[1, :] = False   # an all-masked row degenerates to the uniform distribution in the reference
+    relbias = torch.randn(H, 2 * Lk - 1, generator=g) if mode == 0 else None
+    scale = 1.0 if mode == 0 else 1.0 / math.sqrt(D)
+    ref = attn_ref(bf(q), bf(k), bf(v), kmask, relbias, scale, mode) if prec == "bf16" else attn_ref(q, k, v, kmask, relbias, scale, mode)
+    out = torch.full((B, Lq, H, D), float("nan"), device="cuda")
+    qd, kd, vd, md = q.cuda(), k.cuda(), v.cuda(), kmask.cuda()
+    rd = relbias.cuda() if relbias is not None else None
+    _lib.check(pol._lib.vima_op_attention(pol._handle, ptr(qd), ptr(kd), ptr(vd), ptr(md), ptr(rd), B, H, Lq, Lk, D, scale, mode,
+                                          impl, ptr(out), pol._stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    # bf16: probabilities and outputs are rounded to bf16 (2^-9 relative each)
+    assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)

@@ -1,0 +1,361 @@
+// Attention kernels of the VIMA policy hot path (gfx950, wave64).
+//
+//  * vit_attn      : nn.MultiheadAttention(768, 24) over 5-token crop sequences (vit.py:203,217-231). One thread per
+//                    (crop, query token, head); everything in registers; HBM-bound.
+//  * attn_generic  : exact fp32-softmax attention for any operand type (parity mode + fallback), one wave per query.
+//  * attn_mfma     : bf16 flash attention on the matrix cores (online softmax, fp32 statistics), one wave per
+//                    32 queries x one head, covering the three flavours of the reference:
+//       ATTN_T5     T5Attention.forward (prompt_encoder.py:769-816): NO 1/sqrt(d); + (rel-bias[bucket(j-i)] + mask)
+//       ATTN_CROSS  XAttention.forward (components.py:184-214): /sqrt(d); + (1-mask)*finfo.min key mask
+//       ATTN_CAUSAL Attention._attn (components.py:51-80): /sqrt(d); w*b + -1e4*(1-b) causal fill; + key mask
+//     Masked keys carry the score finfo(fp32).min exactly like the reference (so an all-masked row degenerates to the
+//     same uniform distribution); the -1e4 causal fill is kept literally (no causal tile skipping).
+#include "kernels.h"
+#include <float.h>
+
+namespace vima {
+namespace {
+
+// =============================================================================================== ViT (S <= 8, D = 32)
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, long long total,
+                                                        int S, int W, int heads) {
+  constexpr int D = 32;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int h = (int)(idx % heads);
+  const long long mi = idx / heads;       // m * S + i
+  const long long m = mi / S;
+  const int ld = 3 * W;
+  const T* qp = qkv + mi * ld + h * D;
+  float q[D];
+#pragma unroll
+  for (int c = 0; c < D; c += 4) {
+    const float4 v = load4(qp + c);
+    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
+  }
+  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+  float s[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = -INFINITY;
+    if (j < S) {
+      const T* kp = qkv + (m * S + j) * ld + W + h * D;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; c += 4) {
+        const float4 v = load4(kp + c);
+        d = fmaf(q[c], v.x, d); d = fmaf(q[c + 1], v.y, d); d = fmaf(q[c + 2], v.z, d); d = fmaf(q[c + 3], v.w, d);
+      }
+      s[j] = d * scale;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = j < S ? expf(s[j] - mx) : 0.f;
+    l += s[j];
+  }
+  const float inv = 1.0f / l;
+  float o[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < S) {
+      const T* vp = qkv + (m * S + j) * ld + 2 * W + h * D;
+      const float pj = s[j] * inv;
+#pragma unroll
+      for (int c = 0; c < D; c += 4) {
+        const float4 v = load4(vp + c);
+        o[c] = fmaf(pj, v.x, o[c]); o[c + 1] = fmaf(pj, v.y, o[c + 1]);
+        o[c + 2] = fmaf(pj, v.z, o[c + 2]); o[c + 3] = fmaf(pj, v.w, o[c + 3]);
+      }
+    }
+  }
+  T* op = out + mi * W + h * D;
+#pragma unroll
+  for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
+}
+
+// =============================================================================================== generic exact kernel
+struct AttnDev {
+  const void* q; int ldq;
+  const void* k; int ldk;
+  const void* v; int ldv;
+  void* out; int ldo;
+  const uint8_t* kmask;
+  const float* relbias;
+  int B, H, Lq, Lk;
+  float scale;
+  int mode;
+};
+
+__device__ __forceinline__ float score_fixup(float dot, int mode, float scale, int i, int j, int Lk, bool masked,
+                                             const float* relbias_h) {
+  // literal restatement of the reference's score arithmetic (order of operations preserved)
+  const float madd = masked ? -FLT_MAX : 0.0f;
+  float s;
+  if (mode == ATTN_T5) {
+    s = dot + (relbias_h[(j - i) + Lk - 1] + madd);
+  } else if (mode == ATTN_CROSS) {
+    s = dot * scale + madd;
+  } else {
+    s = dot * scale;
+    if (j > i) s = -1e4f;
+    s = s + madd;
+  }
+  return s;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
+  extern __shared__ float sc[];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const T* qp = reinterpret_cast<const T*>(p.q) + ((long long)b * p.Lq + i) * p.ldq + h * D;
+  float q[D];
+#pragma unroll
+  for (int c = 0; c < D; c += 4) {
+    const float4 v = load4(qp + c);
+    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
+  }
+  const float* rb = p.relbias ? p.relbias + (long long)h * (2 * p.Lk - 1) : nullptr;
+  float mx = -INFINITY;
+  for (int j = lane; j < p.Lk; j += 64) {
+    const T* kp = reinterpret_cast<const T*>(p.k) + ((long long)b * p.Lk + j) * p.ldk + h * D;
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+      const float4 v = load4(kp + c);
+      d = fmaf(q[c], v.x, d); d = fmaf(q[c + 1], v.y, d); d = fmaf(q[c + 2], v.z, d); d = fmaf(q[c + 3], v.w, d);
+    }
+    const bool masked = p.kmask && !p.kmask[(long long)b * p.Lk + j];
+    const float s = score_fixup(d, p.mode, p.scale, i, j, p.Lk, masked, rb);
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float l = 0.f;
+  for (int j = lane; j < p.Lk; j += 64) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  __syncthreads();
+  if (lane < D) {
+    float acc = 0.f;
+    const T* vp = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lk * p.ldv + h * D + lane;
+    for (int j = 0; j < p.Lk; ++j) acc = fmaf(sc[j], Elem<T>::load(vp + (long long)j * p.ldv), acc);
+    T* op = reinterpret_cast<T*>(p.out) + ((long long)b * p.Lq + i) * p.ldo + h * D + lane;
+    Elem<T>::store(op, acc / l);
+  }
+}
+
+// =============================================================================================== MFMA flash attention
+// One wave: 32 queries x all keys of one (batch, head). S^T = K.Q^T is computed with the KEY tile as the MFMA A-operand
+// so that a lane owns one query column: row max / sum are in-lane reductions plus one exchange with lane^32, and the
+// exponentiated scores are ALREADY laid out as the B-operand (P^T) of O^T += V^T.P^T -- no cross-lane shuffle of P.
+// V^T comes from a transposed LDS image of the V tile (rows padded to 72 B: conflict-free ds_read_b64).
+constexpr int VT_STRIDE = 36;  // bf16 elements per Vt row (32 keys + 4 pad)
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
+  __shared__ __attribute__((aligned(16))) bf16_t vt[D * VT_STRIDE];
+  constexpr int KD = D / 16;   // MFMA k-steps over the head dim
+  constexpr int OT = D / 32;   // 32-row tiles of O^T
+  const int lane = threadIdx.x;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q);
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k);
+  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
+
+  const int qi = q0 + l31;
+  const int qrow = qi < p.Lq ? qi : p.Lq - 1;
+  bf16x8_t qf[KD];
+#pragma unroll
+  for (int dd = 0; dd < KD; ++dd) {
+    const uint4 u = *reinterpret_cast<const uint4*>(Q + ((long long)b * p.Lq + qrow) * p.ldq + h * D + dd * 16 + hi * 8);
+    qf[dd] = __builtin_bit_cast(bf16x8_t, u);
+  }
+  f32x16_t ot[OT];
+#pragma unroll
+  for (int it = 0; it < OT; ++it)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* rb = (MODE == ATTN_T5) ? p.relbias + (long long)h * (2 * p.Lk - 1) + (p.Lk - 1) - qi : nullptr;
+  const uint8_t* km = p.kmask ? p.kmask + (long long)b * p.Lk : nullptr;
+
+  for (int k0 = 0; k0 < p.Lk; k0 += 32) {
+    // ---- S^T tile: rows = 32 keys, cols = 32 queries
+    f32x16_t s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      const int krow = (k0 + l31) < p.Lk ? (k0 + l31) : p.Lk - 1;
+      const bf16_t* kp = K + ((long long)b * p.Lk + krow) * p.ldk + h * D + hi * 8;
+#pragma unroll
+      for (int dd = 0; dd < KD; ++dd) {
+        const uint4 u = *reinterpret_cast<const uint4*>(kp + dd * 16);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s, 0, 0, 0);
+      }
+    }
+    // ---- stage V^T of this key tile (previous tile's readers are done: single wave + barrier)
+    __syncthreads();
+#pragma unroll
+    for (int c0 = 0; c0 < (32 * D / 8) / 64; ++c0) {
+      const int c = lane + c0 * 64;
+      const int key = c / (D / 8), dc = c % (D / 8);
+      const int vrow = (k0 + key) < p.Lk ? (k0 + key) : p.Lk - 1;
+      const uint4 u = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lk + vrow) * p.ldv + h * D + dc * 8);
+      const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(dc * 8 + 2 * e) * VT_STRIDE + key] = (bf16_t)(wds[e] & 0xffffu);
+        vt[(dc * 8 + 2 * e + 1) * VT_STRIDE + key] = (bf16_t)(wds[e] >> 16);
+      }
+    }
+    // ---- scores -> probabilities (fp32), online softmax
+    float x[16];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v;
+      if (key < p.Lk) {
+        const float madd = (km && !km[key]) ? -FLT_MAX : 0.0f;
+        if (MODE == ATTN_T5) {
+          v = s[r] + ((qi < p.Lq ? rb[key] : 0.f) + madd);
+        } else if (MODE == ATTN_CROSS) {
+          v = s[r] * p.scale + madd;
+        } else {
+          v = s[r] * p.scale;
+          if (key > qi) v = -1e4f;
+          v = v + madd;
+        }
+      } else {
+        v = -INFINITY;
+      }
+      x[r] = v;
+      mt = fmaxf(mt, v);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __expf(m_run - m_new);
+    uint32_t pk[8];
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __expf(x[r] - m_new), p1 = __expf(x[r + 1] - m_new);
+      const uint32_t u = pack_bf16(p0, p1);
+      pk[r >> 1] = u;
+      rs += __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u);   // sum the ROUNDED weights actually used
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
+    __syncthreads();
+    // ---- O^T += V^T . P^T   (two K=16 MFMAs per 32-row tile of O^T)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 pu;
+      pu.x = pk[half * 4 + 0]; pu.y = pk[half * 4 + 1]; pu.z = pk[half * 4 + 2]; pu.w = pk[half * 4 + 3];
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+      for (int it = 0; it < OT; ++it) {
+        const bf16_t* vr = vt + (it * 32 + l31) * VT_STRIDE + 16 * half + 4 * hi;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(vr);
+        const uint2 a1 = *reinterpret_cast<const uint2*>(vr + 8);
+        uint4 vu;
+        vu.x = a0.x; vu.y = a0.y; vu.z = a1.x; vu.w = a1.y;
+        ot[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vu), pf, ot[it], 0, 0, 0);
+      }
+    }
+  }
+  if (qi < p.Lq) {
+    const float inv = 1.0f / l_run;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + ((long long)b * p.Lq + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = it * 32 + 8 * g + 4 * hi;
+        store4(op + d, make_float4(ot[it][4 * g] * inv, ot[it][4 * g + 1] * inv, ot[it][4 * g + 2] * inv,
+                                   ot[it][4 * g + 3] * inv));
+      }
+  }
+}
+
+inline AttnDev to_dev(const AttnArgs& a) {
+  AttnDev d;
+  d.q = a.q; d.ldq = a.ldq; d.k = a.k; d.ldk = a.ldk; d.v = a.v; d.ldv = a.ldv; d.out = a.out; d.ldo = a.ldo;
+  d.kmask = a.kmask; d.relbias = a.relbias; d.B = a.B; d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk; d.scale = a.scale;
+  d.mode = a.mode;
+  return d;
+}
+
+}  // namespace
+
+int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (S > 8 || W / heads != 32 || W % heads) return (int)hipErrorInvalidValue;
+  const long long total = (long long)M * S * heads;
+  const unsigned g = (unsigned)((total + 255) / 256);
+  if (is_bf16) hipLaunchKernelGGL(vit_attn_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, total, S, W, heads);
+  else hipLaunchKernelGGL(vit_attn_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)qkv, (float*)out, total, S, W, heads);
+  return (int)hipGetLastError();
+}
+
+int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
+  if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
+  if (a.D != 32 && a.D != 64) return (int)hipErrorInvalidValue;
+  if (a.mode == ATTN_T5 && !a.relbias) return (int)hipErrorInvalidValue;
+  const AttnDev d = to_dev(a);
+  dim3 grid((unsigned)a.Lq, (unsigned)a.H, (unsigned)a.B);
+  const size_t sh = (size_t)a.Lk * sizeof(float);
+  if (is_bf16) {
+    if (a.D == 32) hipLaunchKernelGGL((attn_generic_kernel<bf16_t, 32>), grid, dim3(64), sh, st, d);
+    else hipLaunchKernelGGL((attn_generic_kernel<bf16_t, 64>), grid, dim3(64), sh, st, d);
+  } else {
+    if (a.D == 32) hipLaunchKernelGGL((attn_generic_kernel<float, 32>), grid, dim3(64), sh, st, d);
+    else hipLaunchKernelGGL((attn_generic_kernel<float, 64>), grid, dim3(64), sh, st, d);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
+  if (a.D != 32 && a.D != 64) return (int)hipErrorInvalidValue;
+  if (a.mode == ATTN_T5 && !a.relbias) return (int)hipErrorInvalidValue;
+  // 16-byte fragment loads: rows and head offsets must be 16-B aligned
+  if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) return (int)hipErrorInvalidValue;
+  const AttnDev d = to_dev(a);
+  dim3 grid((unsigned)((a.Lq + 31) / 32), (unsigned)a.H, (unsigned)a.B);
+#define VIMA_ATTN(D_, M_) hipLaunchKernelGGL((attn_mfma_kernel<D_, M_>), grid, dim3(64), 0, st, d)
+  if (a.D == 32) {
+    if (a.mode == ATTN_T5) VIMA_ATTN(32, ATTN_T5);
+    else if (a.mode == ATTN_CROSS) VIMA_ATTN(32, ATTN_CROSS);
+    else VIMA_ATTN(32, ATTN_CAUSAL);
+  } else {
+    if (a.mode == ATTN_T5) VIMA_ATTN(64, ATTN_T5);
+    else if (a.mode == ATTN_CROSS) VIMA_ATTN(64, ATTN_CROSS);
+    else VIMA_ATTN(64, ATTN_CAUSAL);
+  }
+#undef VIMA_ATTN
+  return (int)hipGetLastError();
+}
+
+}  // namespace vima

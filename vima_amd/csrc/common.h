@@ -1,0 +1,83 @@
+// Common device/host helpers for the VIMA MI355X (gfx950 / CDNA4) hot path.
+// Wavefront = 64 lanes everywhere in this code base; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vima {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits (activations / weights operand type in bf16 mode)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+  static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+};
+
+// 4 consecutive elements <-> float4
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  float4 r;
+  r.x = __uint_as_float(u.x << 16);
+  r.y = __uint_as_float(u.x & 0xffff0000u);
+  r.z = __uint_as_float(u.y << 16);
+  r.w = __uint_as_float(u.y & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, float4 v) {
+  uint2 u;
+  u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+  u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activations (ids shared with the host side)
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICKGELU = 3 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact erf GELU (nn.GELU())
+    case ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));                   // x * sigmoid(1.702 x)
+    default: return v;
+  }
+}
+
+}  // namespace vima

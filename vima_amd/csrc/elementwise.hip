@@ -1,0 +1,442 @@
+// HBM-bound helper kernels of the VIMA policy hot path (gfx950, wave64): normalisation, image patchify,
+// token plumbing. Each cites the reference lines it replaces. fp32 statistics everywhere; the operand type T of
+// the matrix-core GEMMs (bf16, or fp32 in parity mode) only appears at the GEMM-input boundary.
+#include "kernels.h"
+
+namespace vima {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm / T5 RMSNorm: one wave per row, row held in registers (E <= 64*4*MAXV).
+//   nn.LayerNorm eps 1e-5 (components.py:19,21,128,135; vit.py:164,168,204,214) ; HF T5LayerNorm eps 1e-6 (no mean, no bias)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // float4 per lane -> E <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, long long ldin,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int rms, int rows, int E, float* out32, T* outT) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + (long long)row * ldin;
+  const int nv = E >> 2;  // float4 count (E % 4 == 0)
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      v[i] = *reinterpret_cast<const float4*>(x + c * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float mean = 0.f;
+  if (!rms) mean = wave_sum(s) / (float)E;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)E;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x;
+      o.y = (v[i].y - mean) * rstd * g.y;
+      o.z = (v[i].z - mean) * rstd * g.z;
+      o.w = (v[i].w - mean) * rstd * g.w;
+      if (beta) {
+        const float4 bb = *reinterpret_cast<const float4*>(beta + c * 4);
+        o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+      }
+      if (out32) store4(out32 + (long long)row * E + c * 4, o);
+      if (outT) store4(outT + (long long)row * E + c * 4, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in, T* out, long long n4) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < n4; i += stride) store4(out + i * 4, *reinterpret_cast<const float4*>(in + i * 4));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patchify + normalise: basic_image_tensor_preprocess (preprocess.py:38-43: /255, (x-mean)/std with vit.py:9-10) and the
+// im2col of the 16x16 stride-16 conv (vit.py:151-157,172). One thread per 16 contiguous pixels of one patch row.
+// out row = crop*4 + (gy*2+gx) ; column k = c*256 + py*16 + px  (conv1.weight [768,3,16,16] flattened)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict__ crops, T* out, long long total) {
+  // total = M * 3 * 32 * 2 segments of 16 pixels
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int gx = (int)(i & 1);
+  const int y = (int)((i >> 1) & 31);
+  const int c = (int)((i >> 6) % 3);
+  const long long m = i / 192;
+  const uint4 px = *reinterpret_cast<const uint4*>(crops + ((m * 3 + c) * 32 + y) * 32 + gx * 16);
+  const float mean = c == 0 ? 0.3471f : (c == 1 ? 0.3429f : 0.3383f);
+  const float sd = c == 0 ? 0.3011f : (c == 1 ? 0.2961f : 0.2956f);
+  const int gy = y >> 4, py = y & 15;
+  T* o = out + (m * 4 + gy * 2 + gx) * 768 + c * 256 + py * 16;
+  const uint32_t wds[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 f;
+    f.x = ((float)(wds[j] & 0xff) / 255.0f - mean) / sd;
+    f.y = ((float)((wds[j] >> 8) & 0xff) / 255.0f - mean) / sd;
+    f.z = ((float)((wds[j] >> 16) & 0xff) / 255.0f - mean) / sd;
+    f.w = ((float)(wds[j] >> 24) / 255.0f - mean) / sd;
+    store4(o + j * 4, f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ViT token embed: x[m, t, :] = ln_pre( (t == 0 ? cls : patch[m, t-1]) + pos[t] )   (vit.py:176-180). W = 768 fixed.
+// One wave per token row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_embed_kernel(const float* __restrict__ pre, const float* __restrict__ cls,
+                                                         const float* __restrict__ pos, const float* __restrict__ g,
+                                                         const float* __restrict__ b, float* x, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long m = row / 5;
+  const int t = (int)(row % 5);
+  const float* src = t == 0 ? cls : pre + (m * 4 + (t - 1)) * 768;
+  float4 v[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = (lane + i * 64) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(src + c);
+    const float4 p = *reinterpret_cast<const float4*>(pos + t * 768 + c);
+    v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / 768.0f;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += (a * a + bb * bb) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / 768.0f + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = (lane + i * 64) * 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+    o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+    o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+    o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+    *reinterpret_cast<float4*>(x + row * 768 + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bbox MLP layer 1 (obj_encoder.py:79-86, nn/utils.py build_mlp): relu(W[N,4] . (bbox / [256,128,128,256]) + b)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bbox_l1_kernel(const long long* __restrict__ bbox, const float* __restrict__ W,
+                                                       const float* __restrict__ b, T* out, int R, int N) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)R * N) return;
+  const int r = (int)(i / N), n = (int)(i % N);
+  const float x0 = (float)bbox[r * 4 + 0] / 256.0f;
+  const float x1 = (float)bbox[r * 4 + 1] / 128.0f;
+  const float x2 = (float)bbox[r * 4 + 2] / 128.0f;
+  const float x3 = (float)bbox[r * 4 + 3] / 256.0f;
+  const float4 w = *reinterpret_cast<const float4*>(W + n * 4);
+  float v = x0 * w.x;
+  v = fmaf(x1, w.y, v);
+  v = fmaf(x2, w.z, v);
+  v = fmaf(x3, w.w, v);
+  v += b[n];
+  Elem<T>::store(out + (long long)r * N + n, fmaxf(v, 0.f));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// action embedding layer 1 (vima_policy.py:301-322 de-discretise, action_embd.py:40-56): x = idx / bins,
+// relu(W[256,K] x + b); bins: position (K=2) -> [50, 100]; rotation (K=4) -> 50
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void action_l1_kernel(const long long* __restrict__ idx, int K,
+                                                         const float* __restrict__ W, const float* __restrict__ b, T* out,
+                                                         int R, int ldo, int col0) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)R * 256) return;
+  const int r = (int)(i >> 8), n = (int)(i & 255);
+  float v = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float bins = (K == 2 && k == 1) ? 100.0f : 50.0f;
+    const float x = (float)idx[(long long)r * K + k] / bins;
+    v = k == 0 ? x * W[n * K] : fmaf(x, W[n * K + k], v);
+  }
+  v += b[n];
+  Elem<T>::store(out + (long long)r * ldo + col0 + n, fmaxf(v, 0.f));
+}
+
+__global__ __launch_bounds__(256) void add_row_table_kernel(float* out, long long total4, int E4,
+                                                             const float* __restrict__ table,
+                                                             const long long* __restrict__ sel, int group) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const long long r = i / E4;
+  const int c = (int)(i % E4);
+  long long s = sel[r / group];
+  s = s < 0 ? 0 : (s > 1 ? 1 : s);
+  float4 o = *reinterpret_cast<float4*>(out + i * 4);
+  const float4 t = *reinterpret_cast<const float4*>(table + s * (E4 * 4) + c * 4);
+  o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+  *reinterpret_cast<float4*>(out + i * 4) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// prompt assembly (vima_policy.py:168-233 python loops): row (b,l) source code in tok_src:
+//   >= 0 : index into word_ids (token row = word_table[word_ids[i]])   (word_embd.py:18-23)
+//   -1   : padding (zeros, mask False)
+//   <= -2: object token row  -(v + 2) of obj_tokens / obj_mask
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prompt_assemble_kernel(const int* __restrict__ tok_src,
+                                                               const long long* __restrict__ word_ids,
+                                                               const float* __restrict__ word_table,
+                                                               const float* __restrict__ obj_tokens,
+                                                               const uint8_t* __restrict__ obj_mask, float* x,
+                                                               uint8_t* mask, int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int s = tok_src[row];
+  const float* src = nullptr;
+  uint8_t m = 0;
+  if (s >= 0) {
+    src = word_table + word_ids[s] * E;
+    m = 1;
+  } else if (s <= -2) {
+    const long long o = -(long long)s - 2;
+    src = obj_tokens + o * E;
+    m = obj_mask[o] ? 1 : 0;
+  }
+  for (int c = lane * 4; c < E; c += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src) v = *reinterpret_cast<const float4*>(src + c);
+    *reinterpret_cast<float4*>(x + (long long)row * E + c) = v;
+  }
+  if (lane == 0) mask[row] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decoder input (vima_policy.py:124-146 + xattn_gpt.py:101-106): per batch element b, sequence position l:
+//   step t = l / (Q+1), slot s = l % (Q+1); s < Q -> obs token (t,b,s) else action token (t,b); action mask = True
+//   position id = cumsum(mask)[l] - 1 ; x = token + positions_embed[pos]
+// One workgroup (256 threads) per batch element; Lq <= 512 positions scanned by wave 0 in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict__ obs_tok,
+                                                         const uint8_t* __restrict__ obs_mask,
+                                                         const float* __restrict__ act_tok,
+                                                         const float* __restrict__ pos_table, int n_pos, float* x32,
+                                                         T* xT, uint8_t* mask, int Tn, int B, int Q, int L_act, int E) {
+  __shared__ int pos_s[512];
+  const int b = blockIdx.x;
+  const int Lq = Tn * Q + L_act;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int l = 0; l < Lq; ++l) {
+      const int t = l / (Q + 1), s = l % (Q + 1);
+      const int mk = s < Q ? (obs_mask[((long long)t * B + b) * Q + s] ? 1 : 0) : 1;
+      run += mk;
+      int p = run - 1;
+      p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);   // reference raises on -1 (first token masked); host validates
+      pos_s[l] = p;
+      mask[(long long)b * Lq + l] = (uint8_t)mk;
+    }
+  }
+  __syncthreads();
+  const int e4 = E >> 2;
+  for (int i = threadIdx.x; i < Lq * e4; i += 256) {
+    const int l = i / e4, c = (i % e4) * 4;
+    const int t = l / (Q + 1), s = l % (Q + 1);
+    const float* src = s < Q ? obs_tok + (((long long)t * B + b) * Q + s) * E : act_tok + ((long long)t * B + b) * E;
+    const float4 a = *reinterpret_cast<const float4*>(src + c);
+    const float4 p = *reinterpret_cast<const float4*>(pos_table + (long long)pos_s[l] * E + c);
+    const float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    const long long off = ((long long)b * Lq + l) * E + c;
+    store4(x32 + off, o);
+    if (xT) store4(xT + off, o);
+  }
+}
+
+// prompt + xattn_positions_embed[cumsum(prompt_mask) - 1]  (vima_policy.py:147, xattn_gpt.py:110-114) -> T [B, Lp, E]
+template <typename T>
+__global__ __launch_bounds__(256) void prompt_pos_kernel(const float* __restrict__ prompt, long long sb, long long sl,
+                                                          const uint8_t* __restrict__ mask,
+                                                          const float* __restrict__ pos_table, int n_pos, T* out, int B,
+                                                          int Lp, int E) {
+  extern __shared__ int pos_dyn[];
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int l = 0; l < Lp; ++l) {
+      run += mask[(long long)b * Lp + l] ? 1 : 0;
+      int p = run - 1;
+      p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+      pos_dyn[l] = p;
+    }
+  }
+  __syncthreads();
+  const int e4 = E >> 2;
+  for (int i = threadIdx.x; i < Lp * e4; i += 256) {
+    const int l = i / e4, c = (i % e4) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(prompt + b * sb + l * sl + c);
+    const float4 p = *reinterpret_cast<const float4*>(pos_table + (long long)pos_dyn[l] * E + c);
+    store4(out + ((long long)b * Lp + l) * E + c, make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w));
+  }
+}
+
+// predicted_action_tokens = tokens_out[Q-1 :: Q+1]  (vima_policy.py:158) -> [T, B, E]
+__global__ __launch_bounds__(256) void gather_pred_kernel(const float* __restrict__ x, float* out, int Tn, int B, int Q,
+                                                           int Lq, int E) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int e4 = E >> 2;
+  if (i >= (long long)Tn * B * e4) return;
+  const int c = (int)(i % e4) * 4;
+  const long long tb = i / e4;
+  const int b = (int)(tb % B), t = (int)(tb / B);
+  const int l = (Q - 1) + (Q + 1) * t;
+  *reinterpret_cast<float4*>(out + tb * E + c) = *reinterpret_cast<const float4*>(x + ((long long)b * Lq + l) * E + c);
+}
+
+inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
+                     int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (E % 4 != 0 || E > 64 * 4 * LN_MAXV || ldin % 4 != 0) return (int)hipErrorInvalidValue;
+  if (is_bf16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, rms,
+                       rows, E, out32, (bf16_t*)outT);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, rms,
+                       rows, E, out32, (float*)outT);
+  return (int)hipGetLastError();
+}
+
+int launch_cast(const float* in, void* outT, long long n, bool is_bf16, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (n % 4) return (int)hipErrorInvalidValue;
+  const long long n4 = n / 4;
+  unsigned g = nblk(n4, 256);
+  if (g > 8192) g = 8192;
+  if (is_bf16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(g), dim3(256), 0, st, in, (bf16_t*)outT, n4);
+  else hipLaunchKernelGGL(cast_kernel<float>, dim3(g), dim3(256), 0, st, in, (float*)outT, n4);
+  return (int)hipGetLastError();
+}
+
+int launch_patchify(const uint8_t* crops, void* outT, int M, bool is_bf16, hipStream_t st) {
+  if (M <= 0) return 0;
+  const long long total = (long long)M * 192;
+  if (is_bf16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(nblk(total, 256)), dim3(256), 0, st, crops, (bf16_t*)outT, total);
+  else hipLaunchKernelGGL(patchify_kernel<float>, dim3(nblk(total, 256)), dim3(256), 0, st, crops, (float*)outT, total);
+  return (int)hipGetLastError();
+}
+
+int launch_vit_embed(const float* pre, const float* cls, const float* pos, const float* g, const float* b, float* x,
+                     int M, hipStream_t st) {
+  if (M <= 0) return 0;
+  const long long rows = (long long)M * 5;
+  hipLaunchKernelGGL(vit_embed_kernel, dim3(nblk(rows, 4)), dim3(256), 0, st, pre, cls, pos, g, b, x, rows);
+  return (int)hipGetLastError();
+}
+
+int launch_bbox_l1(const long long* bbox, const float* W, const float* b, void* outT, int R, int Nout, bool is_bf16,
+                   hipStream_t st) {
+  if (R <= 0) return 0;
+  const long long total = (long long)R * Nout;
+  if (is_bf16) hipLaunchKernelGGL(bbox_l1_kernel<bf16_t>, dim3(nblk(total, 256)), dim3(256), 0, st, bbox, W, b, (bf16_t*)outT, R, Nout);
+  else hipLaunchKernelGGL(bbox_l1_kernel<float>, dim3(nblk(total, 256)), dim3(256), 0, st, bbox, W, b, (float*)outT, R, Nout);
+  return (int)hipGetLastError();
+}
+
+int launch_action_l1(const long long* idx, int K, const float* W, const float* b, void* outT, int R, int ldo, int col0,
+                     bool is_bf16, hipStream_t st) {
+  if (R <= 0) return 0;
+  const long long total = (long long)R * 256;
+  if (is_bf16) hipLaunchKernelGGL(action_l1_kernel<bf16_t>, dim3(nblk(total, 256)), dim3(256), 0, st, idx, K, W, b, (bf16_t*)outT, R, ldo, col0);
+  else hipLaunchKernelGGL(action_l1_kernel<float>, dim3(nblk(total, 256)), dim3(256), 0, st, idx, K, W, b, (float*)outT, R, ldo, col0);
+  return (int)hipGetLastError();
+}
+
+int launch_add_row_table(float* out, int rows, int E, const float* table, const long long* sel, int group,
+                         hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (E % 4) return (int)hipErrorInvalidValue;
+  const long long total4 = (long long)rows * (E / 4);
+  hipLaunchKernelGGL(add_row_table_kernel, dim3(nblk(total4, 256)), dim3(256), 0, st, out, total4, E / 4, table, sel, group);
+  return (int)hipGetLastError();
+}
+
+int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const float* word_table,
+                           const float* obj_tokens, const uint8_t* obj_mask, float* x, uint8_t* mask, int rows, int E,
+                           hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (E % 4) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(prompt_assemble_kernel, dim3(nblk(rows, 4)), dim3(256), 0, st, tok_src, word_ids, word_table,
+                     obj_tokens, obj_mask, x, mask, rows, E);
+  return (int)hipGetLastError();
+}
+
+int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table,
+                     int n_pos, float* x32, void* xT, uint8_t* mask, int T, int B, int Q, int L_act, int E, bool is_bf16,
+                     hipStream_t st) {
+  if (B <= 0) return 0;
+  if (T * Q + L_act > 512 || E % 4) return (int)hipErrorInvalidValue;
+  if (is_bf16)
+    hipLaunchKernelGGL(dec_embed_kernel<bf16_t>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
+                       x32, (bf16_t*)xT, mask, T, B, Q, L_act, E);
+  else
+    hipLaunchKernelGGL(dec_embed_kernel<float>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
+                       x32, (float*)xT, mask, T, B, Q, L_act, E);
+  return (int)hipGetLastError();
+}
+
+int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uint8_t* mask, const float* pos_table,
+                      int n_pos, void* outT, int B, int Lp, int E, bool is_bf16, hipStream_t st) {
+  if (B <= 0 || Lp <= 0) return 0;
+  if (E % 4 || sb % 4 || sl % 4) return (int)hipErrorInvalidValue;
+  const size_t sh = (size_t)Lp * sizeof(int);
+  if (is_bf16)
+    hipLaunchKernelGGL(prompt_pos_kernel<bf16_t>, dim3(B), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
+                       (bf16_t*)outT, B, Lp, E);
+  else
+    hipLaunchKernelGGL(prompt_pos_kernel<float>, dim3(B), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
+                       (float*)outT, B, Lp, E);
+  return (int)hipGetLastError();
+}
+
+int launch_gather_pred(const float* x, float* out, int T, int B, int Q, int Lq, int E, hipStream_t st) {
+  const long long total = (long long)T * B * (E / 4);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(gather_pred_kernel, dim3(nblk(total, 256)), dim3(256), 0, st, x, out, T, B, Q, Lq, E);
+  return (int)hipGetLastError();
+}
+
+}  // namespace vima

@@ -1,0 +1,319 @@
+// MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+//
+// Replaces every nn.Linear / HF Conv1D / `@ projection` / patch-embed conv of the reference hot path
+// (e.g. components.py:167,175,217,221-226, vit.py:172,189, prompt_encoder.py q/k/v/o,
+// T5DenseActDense wi/wo, nn/utils.py build_mlp Linear layers).
+//
+// Design (CDNA4, wave64):
+//  * 128x128 output tile per 256-thread workgroup (4 waves as 2(m) x 2(n), 64x64 per wave = 2x2 MFMA 32x32 tiles).
+//  * K is consumed in 128-BYTE row slices (64 bf16 / 32 fp32): each tile row is 8 x 16 B chunks.
+//  * global -> LDS with `global_load_lds_dwordx4` (no VGPR round trip). The LDS image is lane-linear, so the
+//    bank-conflict swizzle is applied on the SOURCE address: LDS slot (row r, position p) receives global chunk
+//    c = p ^ ((r >> 1) & 7); fragments are read back with ds_read_b128 at position c ^ ((r >> 1) & 7).
+//    With 128-B rows every 16-lane ds_read_b128 group then touches 16 distinct 16-B slots of the 256-B bank row.
+//  * 2 LDS stages (2 x 32 KiB); the next K-slice is issued before the MFMAs of the current one and waited for
+//    with ONE `s_waitcnt vmcnt(0)` + `s_barrier` per K-slice (2 workgroups/CU hide the rest).
+//  * operands are fed SWAPPED to the matrix core (W fragment as A-operand, activation fragment as B-operand) so a
+//    lane ends up holding 4 CONSECUTIVE output columns of one output row -> 8/16-byte vector epilogue
+//    (bias / activation / GEGLU gate multiply / residual / dual fp32+bf16 store) instead of scalar stores.
+//  * blockIdx -> tile mapping is XCD-aware: consecutive workgroups on one XCD (blockIdx % 8) walk the n-tiles of
+//    the same 128-row A panel, so the panel is fetched from HBM once per XCD L2.
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace vima {
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;                 // bytes of K per tile row
+constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A tile + W tile
+constexpr int NSTAGE = 2;
+constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;
+
+template <typename T> struct KCfg;
+template <> struct KCfg<bf16_t> { static constexpr int BK = 64; static constexpr int EPC = 8; };  // elems / 16-B chunk
+template <> struct KCfg<float> { static constexpr int BK = 32; static constexpr int EPC = 4; };
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Same LDS-DMA hidden from hipcc's waitcnt bookkeeping: the compiler otherwise drains vmcnt(0) in front of the first
+// ds_read of every K-slice (it cannot prove the DMA target stage and the stage being read are disjoint), which
+// serialises load and MFMA inside a wave. M0 carries the wave-uniform LDS byte address and is written in the same
+// statement that uses it (hipcc reserves M0 and does not preserve it across statements).
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+// wait for this wave's outstanding LDS-DMA + LDS reads, then workgroup barrier (compiler memory barrier too)
+__device__ __forceinline__ void wait_all_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
+    const int c = kk * 2 + hi;
+    v = *reinterpret_cast<const uint4*>(tile + r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4));
+  }
+};
+template <> struct Frag<float> {
+  float4 v0, v1;
+  __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
+    const int c = kk * 4 + hi * 2;
+    const int s = (r >> 1) & 7;
+    v0 = *reinterpret_cast<const float4*>(tile + r * ROW_BYTES + ((c ^ s) << 4));
+    v1 = *reinterpret_cast<const float4*>(tile + r * ROW_BYTES + (((c + 1) ^ s) << 4));
+  }
+};
+
+__device__ __forceinline__ f32x16_t mma(const Frag<bf16_t>& w, const Frag<bf16_t>& a, f32x16_t acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w.v), __builtin_bit_cast(bf16x8_t, a.v),
+                                                 acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mma(const Frag<float>& w, const Frag<float>& a, f32x16_t acc) {
+  // lane (i = lane&31, hi = lane>>5) holds k = hi*8 + e, e = 0..7 ; MFMA e contracts k in {e, 8+e}
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v0.x, a.v0.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v0.y, a.v0.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v0.z, a.v0.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v0.w, a.v0.w, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v1.x, a.v1.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v1.y, a.v1.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v1.z, a.v1.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v1.w, a.v1.w, acc, 0, 0, 0);
+  return acc;
+}
+
+struct GemmDev {
+  const void* A; const void* W;
+  int M, N, K, lda, ldw;
+  long long bsA, bsW, bsBias, bsMul, bsRes, bs32, bsT;
+  const float* bias; int act;
+  const void* mul; int ldmul;
+  const float* res; int ldres;
+  float* out32; int ld32;
+  void* outT; int ldT;
+  int rb, s_hi, s_lo, ro;
+  int mtiles, ntiles;
+  int vec_ok;   // all pointers/strides allow 4-wide vector epilogue
+};
+
+// ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
+template <typename T, int ACT, bool VEC, bool ASMLDS>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = KCfg<T>::BK;
+  constexpr int EPC = KCfg<T>::EPC;
+  constexpr int KSTEPS = BK / 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  // XCD-aware tile mapping (block b runs on XCD b % 8): one XCD walks all n-tiles of its A panel back to back
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int idx = bid >> 3;
+  const int tn = idx % p.ntiles;
+  const int tm = (idx / p.ntiles) * 8 + xcd;
+  if (tm >= p.mtiles) return;
+  const int z = blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const T* A = reinterpret_cast<const T*>(p.A) + (long long)z * p.bsA;
+  const T* W = reinterpret_cast<const T*>(p.W) + (long long)z * p.bsW;
+
+  // per-lane source pointers of the 4 (A) + 4 (W) LDS-DMA pieces of one K-slice
+  const T* srcA[4];
+  const T* srcW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = (i * 4 + w) * 64 + lane;
+    const int r = s >> 3, pp = s & 7;
+    const int c = pp ^ ((r >> 1) & 7);
+    int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
+    int rw = n0 + r; rw = rw < p.N ? rw : p.N - 1;
+    srcA[i] = A + (long long)ra * p.lda + c * EPC;
+    srcW[i] = W + (long long)rw * p.ldw + c * EPC;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  const int wm = w >> 1, wn = w & 1;
+  const int nk = p.K / BK;
+
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue = [&](int stage, int kt) {
+    if constexpr (ASMLDS) {
+      const unsigned sA = smem_base + stage * STAGE_BYTES + w * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16_asm(srcA[i] + kt * BK, sA + i * 4096);
+        glds16_asm(srcW[i] + kt * BK, sA + TILE_BYTES + i * 4096);
+      }
+    } else {
+      char* sA = smem + stage * STAGE_BYTES;
+      char* sW = sA + TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16(srcA[i] + kt * BK, sA + (i * 4 + w) * 1024);
+        glds16(srcW[i] + kt * BK, sW + (i * 4 + w) * 1024);
+      }
+    }
+  };
+
+  issue(0, 0);
+  wait_all_and_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+    const char* sA = smem + cur * STAGE_BYTES;
+    const char* sW = sA + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      Frag<T> fa[2], fw[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) fa[mi].load(sA, wm * 64 + mi * 32 + l31, kk, hi);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fw[ni].load(sW, wn * 64 + ni * 32 + l31, kk, hi);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mma(fw[ni], fa[mi], acc[mi][ni]);
+    }
+    wait_all_and_barrier();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // acc[mi][ni][4q+e] = C[m = m0 + wm*64 + mi*32 + l31][n = n0 + wn*64 + ni*32 + 8q + 4hi + e]
+  const float* bias = p.bias ? p.bias + (long long)z * p.bsBias : nullptr;
+  const T* mul = p.mul ? reinterpret_cast<const T*>(p.mul) + (long long)z * p.bsMul : nullptr;
+  const float* res = p.res ? p.res + (long long)z * p.bsRes : nullptr;
+  float* out32 = p.out32 ? p.out32 + (long long)z * p.bs32 : nullptr;
+  T* outT = p.outT ? reinterpret_cast<T*>(p.outT) + (long long)z * p.bsT : nullptr;
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= p.M) continue;
+    long long orow = m;
+    if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
+        const int act = ACT >= 0 ? ACT : p.act;
+        if constexpr (VEC) {   // N % 4 == 0 => n + 3 < N
+          if (bias) { const float4 b = load4(bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+          if (act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+          }
+          if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w; }
+          if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+          const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (out32) store4(out32 + orow * p.ld32 + n, o);
+          if (outT) store4(outT + orow * p.ldT + n, o);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ne = n + e;
+            if (ne >= p.N) break;
+            float x = v[e];
+            if (bias) x += bias[ne];
+            x = apply_act(x, act);
+            if (mul) x *= Elem<T>::load(mul + (long long)m * p.ldmul + ne);
+            if (res) x += res[(long long)m * p.ldres + ne];
+            if (out32) out32[orow * p.ld32 + ne] = x;
+            if (outT) Elem<T>::store(outT + orow * p.ldT + ne, x);
+          }
+        }
+      }
+    }
+  }
+}
+
+// 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin. Override with VIMA_GEMM_VARIANT for A/B runs.
+int g_gemm_variant = -1;
+inline int gemm_variant() {
+  if (g_gemm_variant < 0) {
+    const char* e = getenv("VIMA_GEMM_VARIANT");
+    g_gemm_variant = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_gemm_variant;
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename T>
+int launch_t(const GemmArgs& a, hipStream_t st) {
+  constexpr int BK = KCfg<T>::BK;
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.K <= 0 || a.K % BK != 0) return (int)hipErrorInvalidValue;
+  // LDS-DMA reads 16-B chunks: rows must start 16-B aligned
+  const size_t es = sizeof(T);
+  if (!aligned_to(a.A, 16) || !aligned_to(a.W, 16) || (a.lda * es) % 16 || (a.ldw * es) % 16 ||
+      (a.bsA * es) % 16 || (a.bsW * es) % 16)
+    return (int)hipErrorInvalidValue;
+  GemmDev d;
+  d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
+  d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
+  d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
+  d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
+  d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
+  d.mtiles = (a.M + BM - 1) / BM;
+  d.ntiles = (a.N + BN - 1) / BN;
+  bool v = (a.N % 4 == 0);
+  if (a.bias) v = v && aligned_to(a.bias, 16) && (a.bsBias % 4 == 0);
+  if (a.mul) v = v && aligned_to(a.mul, 4 * es) && (a.ldmul % 4 == 0) && (a.bsMul % 4 == 0);
+  if (a.res) v = v && aligned_to(a.res, 16) && (a.ldres % 4 == 0) && (a.bsRes % 4 == 0);
+  if (a.out32) v = v && aligned_to(a.out32, 16) && (a.ld32 % 4 == 0) && (a.bs32 % 4 == 0);
+  if (a.outT) v = v && aligned_to(a.outT, 4 * es) && (a.ldT % 4 == 0) && (a.bsT % 4 == 0);
+  d.vec_ok = v ? 1 : 0;
+  const int groups = (d.mtiles + 7) / 8;
+  dim3 grid((unsigned)(groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  const bool asmlds = gemm_variant() == 1;
+#define VIMA_GEMM_LAUNCH(ACT_, VEC_)                                                                       \
+  do {                                                                                                     \
+    if (asmlds) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, true>), grid, dim3(256), SMEM_BYTES, st, d); \
+    else hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, false>), grid, dim3(256), SMEM_BYTES, st, d);       \
+  } while (0)
+  if (!v) VIMA_GEMM_LAUNCH(-1, false);
+  else if (a.act == ACT_NONE) VIMA_GEMM_LAUNCH(ACT_NONE, true);
+  else if (a.act == ACT_RELU) VIMA_GEMM_LAUNCH(ACT_RELU, true);
+  else if (a.act == ACT_GELU) VIMA_GEMM_LAUNCH(ACT_GELU, true);
+  else if (a.act == ACT_QUICKGELU) VIMA_GEMM_LAUNCH(ACT_QUICKGELU, true);
+  else return (int)hipErrorInvalidValue;
+#undef VIMA_GEMM_LAUNCH
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st) {
+  return is_bf16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
+}
+void set_gemm_variant(int v) { g_gemm_variant = v; }
+int gemm_k_multiple(bool is_bf16) { return is_bf16 ? KCfg<bf16_t>::BK : KCfg<float>::BK; }
+
+}  // namespace vima

@@ -1,0 +1,92 @@
+// Launcher declarations for the hand-written gfx950 kernels (definitions in *.hip).
+#pragma once
+#include "common.h"
+
+namespace vima {
+
+// ---------------------------------------------------------------- GEMM
+// C[M,N] = epilogue( A[M,K] . W[N,K]^T ), fp32 accumulation on the matrix cores.
+//   epilogue(v) = ((act(v + bias[n])) * mul[r][n]) + res[r][n]
+// Operand type T (A, W, mul, outT) is bf16 (mfma_f32_32x32x16_bf16) or float
+// (mfma_f32_32x32x2_f32, exact-fp32 parity mode).
+struct GemmArgs {
+  const void* A = nullptr;   // [M,K] row-major, row stride lda (elements)
+  const void* W = nullptr;   // [N,K] row-major (nn.Linear layout), row stride ldw
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldw = 0;
+  int batch = 1;             // blockIdx.y; strides below in elements
+  long long bsA = 0, bsW = 0, bsBias = 0, bsMul = 0, bsRes = 0, bs32 = 0, bsT = 0;
+  const float* bias = nullptr;
+  int act = ACT_NONE;
+  const void* mul = nullptr;  // T [M, ldmul]
+  int ldmul = 0;
+  const float* res = nullptr; // fp32 [M, ldres]  (may alias out32: each element is read then written by one thread)
+  int ldres = 0;
+  float* out32 = nullptr;
+  int ld32 = 0;
+  void* outT = nullptr;
+  int ldT = 0;
+  // output-row remap (outputs only): orow = (r / rb) * s_hi + (r % rb) * s_lo + ro ; rb == 0 -> identity
+  int rb = 0, s_hi = 0, s_lo = 0, ro = 0;
+};
+// returns hipError_t as int; is_bf16 selects the operand type
+int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
+int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
+void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin
+
+// ---------------------------------------------------------------- normalisation / elementwise
+// LayerNorm (rms=0: mean/var, affine) or T5 RMSNorm (rms=1: no mean, no bias). fp32 statistics.
+// in: fp32 rows of length E at row stride ldin; outputs optional.
+int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
+                     int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
+int launch_cast(const float* in, void* outT, long long n, bool is_bf16, hipStream_t st);
+
+// uint8 crops [M,3,32,32] -> normalised patch matrix T [M*4, 768], k = c*256 + py*16 + px (conv1 weight order)
+int launch_patchify(const uint8_t* crops, void* outT, int M, bool is_bf16, hipStream_t st);
+// tokens = LN_pre(concat(cls, patches) + pos): pre fp32 [M*4,768] -> x fp32 [M*5,768]
+int launch_vit_embed(const float* pre, const float* cls, const float* pos, const float* g, const float* b,
+                     float* x, int M, hipStream_t st);
+// first bbox-MLP layer: relu(W[768,4] . (bbox/[256,128,128,256]) + b) -> T [R,768]
+int launch_bbox_l1(const long long* bbox, const float* W, const float* b, void* outT, int R, int Nout,
+                   bool is_bf16, hipStream_t st);
+// first action-embedding layer for one key: x = idx / bins ; relu(W[256,K] x + b) -> T [R, ldo] at column col0
+int launch_action_l1(const long long* idx, int K, const float* W, const float* b, void* outT, int R, int ldo,
+                     int col0, bool is_bf16, hipStream_t st);
+// out[r, :] += table[sel[r / group]][:]   (obs_fusion end-effector term)
+int launch_add_row_table(float* out, int rows, int E, const float* table, const long long* sel, int group,
+                         hipStream_t st);
+// prompt assembly: x[b,l,:] = word table row / object token / 0 ; mask likewise
+int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const float* word_table,
+                           const float* obj_tokens, const uint8_t* obj_mask, float* x, uint8_t* mask, int rows,
+                           int E, hipStream_t st);
+// decoder input: interleave [o_1..o_Q, a] per step, cumsum position ids, + positions_embed
+int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table,
+                     int n_pos, float* x32, void* xT, uint8_t* mask, int T, int B, int Q, int L_act, int E,
+                     bool is_bf16, hipStream_t st);
+// prompt + xattn_positions_embed[cumsum(mask)-1] -> T [B*Lp, E]; input strides in elements (seq-first views ok)
+int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uint8_t* mask, const float* pos_table,
+                      int n_pos, void* outT, int B, int Lp, int E, bool is_bf16, hipStream_t st);
+// out[t,b,:] = x[b, (Q-1) + (Q+1) t, :]
+int launch_gather_pred(const float* x, float* out, int T, int B, int Q, int Lq, int E, hipStream_t st);
+
+// ---------------------------------------------------------------- attention
+// ViT: 5-token (S <= 8) multi-head attention on packed qkv T [M*S, 3*W] -> T [M*S, W]; head dim 32
+int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st);
+
+enum AttnMode : int { ATTN_T5 = 0, ATTN_CROSS = 1, ATTN_CAUSAL = 2 };
+struct AttnArgs {
+  const void* q = nullptr; int ldq = 0;   // row (b*Lq + i), head h at column h*D
+  const void* k = nullptr; int ldk = 0;   // row (b*Lk + j)
+  const void* v = nullptr; int ldv = 0;
+  void* out = nullptr; int ldo = 0;
+  const uint8_t* kmask = nullptr;         // [B, Lk] 1 = attend; masked keys get score finfo(fp32).min
+  const float* relbias = nullptr;         // T5: [H][2*Lk-1], index (j - i) + Lk - 1
+  int B = 0, H = 0, Lq = 0, Lk = 0, D = 0;
+  float scale = 1.0f;
+  int mode = ATTN_CROSS;
+};
+// generic exact kernel (any T); the MFMA flash kernel (bf16, D in {32,64})
+int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st);
+int launch_attn_mfma(const AttnArgs& a, hipStream_t st);
+
+}  // namespace vima

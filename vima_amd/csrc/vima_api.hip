@@ -1,0 +1,1046 @@
+// Host orchestration + C ABI (include/vima_hip.h) of the MI355X-native VIMA policy forward pass.
+// One VimaHandle = packed weights + workspace arena for one (model, device). Every policy method is a fixed
+// sequence of hand-written gfx950 kernels (gemm.hip / attention.hip / elementwise.hip) on the caller's stream.
+#include "../../include/vima_hip.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace vima;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& m, int code = 1) {
+  g_err = m;
+  return code ? code : 1;
+}
+
+#define HIPCK(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e__), (int)e__);                      \
+  } while (0)
+
+#define KCK(expr)                                                                                     \
+  do {                                                                                                \
+    int e__ = (expr);                                                                                 \
+    if (e__ != 0)                                                                                     \
+      return fail(std::string(#expr) + ": " + hipGetErrorString((hipError_t)e__) + " @" + __func__, e__); \
+  } while (0)
+
+constexpr int kVitW = 768, kVitLayers = 4, kVitHeads = 24;
+constexpr int kT5Layers = 12, kT5Heads = 12, kT5D = 64, kT5FF = 3072, kT5Model = 768, kT5Buckets = 32;
+constexpr int kVocab = 32128;
+constexpr int kHeadHidden = 512, kNumHeadsOut = 12, kLogits = 700;
+const int kHeadBins[kNumHeadsOut] = {50, 100, 50, 50, 50, 50, 50, 100, 50, 50, 50, 50};
+const char* kViews[2] = {"front", "top"};
+const char* kActKeys[4] = {"pose0_position", "pose0_rotation", "pose1_position", "pose1_rotation"};
+const int kActDims[4] = {2, 4, 2, 4};
+
+// HF modeling_t5._relative_position_bucket, bidirectional, 32 buckets, max distance 128 (fp32 log like torch)
+int t5_bucket(int rel) {
+  const int nb = 16, max_exact = 8;
+  int out = rel > 0 ? nb : 0;
+  int n = rel < 0 ? -rel : rel;
+  if (n < max_exact) return out + n;
+  const float ratio = (float)n / (float)max_exact;
+  const float v = logf(ratio) / (float)log(128.0 / 8.0) * (float)(nb - max_exact);
+  int large = max_exact + (int)v;
+  if (large > nb - 1) large = nb - 1;
+  return out + large;
+}
+
+struct HostParam {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct Lin {            // packed nn.Linear-layout weight T [N,K] (+ optional fp32 bias [N])
+  void* W = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;
+};
+
+struct Arena {          // stream-ordered bump allocator; chunks are only released at reset()
+  struct Chunk { char* p; size_t cap; };
+  std::vector<Chunk> chunks;
+  size_t used = 0;      // in the last chunk
+  size_t total_need = 0;
+  int reset() {
+    if (chunks.size() > 1) {   // consolidate so steady state is a single allocation
+      size_t tot = 0;
+      for (auto& c : chunks) tot += c.cap;
+      if (hipDeviceSynchronize() != hipSuccess) return 1;
+      for (auto& c : chunks) (void)hipFree(c.p);
+      chunks.clear();
+      char* p = nullptr;
+      if (hipMalloc((void**)&p, tot) != hipSuccess) return 1;
+      chunks.push_back({p, tot});
+    }
+    used = 0;
+    return 0;
+  }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    if (chunks.empty() || used + bytes > chunks.back().cap) {
+      size_t cap = bytes > ((size_t)64 << 20) ? bytes : ((size_t)64 << 20);
+      char* p = nullptr;
+      if (hipMalloc((void**)&p, cap) != hipSuccess) return nullptr;
+      chunks.push_back({p, cap});
+      used = 0;
+    }
+    void* r = chunks.back().p + used;
+    used += bytes;
+    return r;
+  }
+  size_t bytes() const {
+    size_t t = 0;
+    for (auto& c : chunks) t += c.cap;
+    return t;
+  }
+  void release() {
+    for (auto& c : chunks) (void)hipFree(c.p);
+    chunks.clear();
+  }
+};
+
+struct ProfRec { int cls; hipEvent_t a, b; double flops; };
+
+}  // namespace
+
+struct VimaHandle {
+  VimaConfig cfg;
+  int device = 0;
+  bool bf16 = true;
+  bool finalized = false;
+  int attn_impl = 1;
+  int vit_chunk = 16384;
+  std::map<std::string, HostParam> host;       // staged until finalize
+  std::vector<void*> owned;                     // device allocations of packed weights
+  Arena arena;
+  // ---- packed weights
+  struct VitBlock { float *ln1g, *ln1b, *ln2g, *ln2b; Lin in_proj, out_proj, fc, proj; };
+  struct {
+    float *cls, *pos, *lnpre_g, *lnpre_b, *lnpost_g, *lnpost_b;
+    Lin conv, projection;
+    VitBlock blk[kVitLayers];
+  } vit;
+  struct { float *w0, *b0; Lin l1, l2; Lin pre; } view[2];
+  Lin fuse; float* ee_table = nullptr;           // [2][E]
+  Lin pobj[3];
+  float* word_table = nullptr;                   // [32128,768] fp32
+  struct T5Layer { float *rms1, *rms2; Lin qkv, o, wi, wo; };
+  T5Layer t5[kT5Layers];
+  float* t5_final = nullptr;
+  std::vector<float> t5_relbias_host;            // [32][12]
+  std::map<int, float*> t5_bias_tables;          // L -> device [12][2L-1]
+  Lin t5_post; bool has_t5_post = false;
+  float *pos_emb = nullptr, *xpos_emb = nullptr;
+  struct DecLayer {
+    float *xln_g, *xln_b, *xln2_g, *xln2_b; Lin q, kv, ao, l1, gate, l2;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b; Lin c_attn, c_proj, fc, mgate, mproj;
+  };
+  std::vector<DecLayer> dec;
+  Lin head1; void* head2_W = nullptr; float* head2_b = nullptr; Lin head3[kNumHeadsOut];
+  struct { float *w0, *b0; } act0[4];
+  void* act1_W = nullptr; float* act1_b = nullptr; Lin act_post;
+  // ---- profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+
+  size_t esz() const { return bf16 ? 2 : 4; }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ weight packing
+uint16_t h_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+struct Packer {
+  VimaHandle* h;
+  std::string missing;
+  const HostParam* get(const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = h->host.find(name);
+    if (it == h->host.end()) {
+      missing += "\n  missing key: " + name;
+      return nullptr;
+    }
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+      std::string s = "\n  shape mismatch for " + name + ": got [";
+      for (auto d : it->second.shape) s += std::to_string(d) + ",";
+      s += "] want [";
+      for (auto d : want) s += std::to_string(d) + ",";
+      missing += s + "]";
+      return nullptr;
+    }
+    return &it->second;
+  }
+  float* up_f32(const float* src, size_t n) {
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, n * 4 + 16) != hipSuccess) { missing += "\n  hipMalloc failed"; return nullptr; }
+    h->owned.push_back(d);
+    if (hipMemcpy(d, src, n * 4, hipMemcpyHostToDevice) != hipSuccess) missing += "\n  hipMemcpy failed";
+    return d;
+  }
+  void* up_T(const std::vector<float>& src) {
+    if (!h->bf16) return up_f32(src.data(), src.size());
+    std::vector<uint16_t> t(src.size());
+    for (size_t i = 0; i < src.size(); ++i) t[i] = h_f2bf(src[i]);
+    void* d = nullptr;
+    if (hipMalloc(&d, t.size() * 2 + 16) != hipSuccess) { missing += "\n  hipMalloc failed"; return nullptr; }
+    h->owned.push_back(d);
+    if (hipMemcpy(d, t.data(), t.size() * 2, hipMemcpyHostToDevice) != hipSuccess) missing += "\n  hipMemcpy failed";
+    return d;
+  }
+  float* vec(const std::string& name, int64_t n) {
+    const HostParam* p = get(name, {n});
+    return p ? up_f32(p->data.data(), (size_t)n) : nullptr;
+  }
+  // nn.Linear weight [N,K] (+ bias)
+  Lin linear(const std::string& prefix, int N, int K, bool bias, const char* wname = ".weight") {
+    Lin l;
+    l.N = N; l.K = K;
+    const HostParam* w = get(prefix + wname, {N, K});
+    if (w) l.W = up_T(w->data);
+    if (bias) l.b = vec(prefix + ".bias", N);
+    return l;
+  }
+  // HF Conv1D weight [K(in), N(out)] -> packed [N,K]
+  Lin conv1d(const std::string& prefix, int N, int K) {
+    Lin l;
+    l.N = N; l.K = K;
+    const HostParam* w = get(prefix + ".weight", {K, N});
+    if (w) {
+      std::vector<float> t((size_t)N * K);
+      for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) t[(size_t)n * K + k] = w->data[(size_t)k * N + n];
+      l.W = up_T(t);
+    }
+    l.b = vec(prefix + ".bias", N);
+    return l;
+  }
+};
+
+int pack_all(VimaHandle* h) {
+  Packer P{h, ""};
+  const int E = h->cfg.embed_dim, NL = h->cfg.xf_n_layers;
+  char buf[256];
+  // ---- ViT (vit.py:137-169)
+  const std::string v = "obj_encoder.cropped_img_encoder.vit.";
+  h->vit.cls = P.vec(v + "cls_token", kVitW);
+  if (const HostParam* p = P.get(v + "pos_embed", {5, kVitW})) h->vit.pos = P.up_f32(p->data.data(), p->data.size());
+  h->vit.lnpre_g = P.vec(v + "ln_pre.weight", kVitW);
+  h->vit.lnpre_b = P.vec(v + "ln_pre.bias", kVitW);
+  h->vit.lnpost_g = P.vec(v + "ln_post.weight", kVitW);
+  h->vit.lnpost_b = P.vec(v + "ln_post.bias", kVitW);
+  if (const HostParam* p = P.get(v + "conv1.weight", {kVitW, 3, 16, 16})) {  // [768, 3*16*16] already [N,K]
+    h->vit.conv.N = kVitW; h->vit.conv.K = 768;
+    h->vit.conv.W = P.up_T(p->data);
+  }
+  if (const HostParam* p = P.get(v + "projection", {kVitW, kVitW})) {        // x @ projection: [in,out] -> [out,in]
+    std::vector<float> t((size_t)kVitW * kVitW);
+    for (int k = 0; k < kVitW; ++k)
+      for (int n = 0; n < kVitW; ++n) t[(size_t)n * kVitW + k] = p->data[(size_t)k * kVitW + n];
+    h->vit.projection.N = kVitW; h->vit.projection.K = kVitW;
+    h->vit.projection.W = P.up_T(t);
+  }
+  for (int j = 0; j < kVitLayers; ++j) {
+    snprintf(buf, sizeof buf, "%sblocks.%d.", v.c_str(), j);
+    const std::string b = buf;
+    auto& B = h->vit.blk[j];
+    B.ln1g = P.vec(b + "ln_1.weight", kVitW); B.ln1b = P.vec(b + "ln_1.bias", kVitW);
+    B.ln2g = P.vec(b + "ln_2.weight", kVitW); B.ln2b = P.vec(b + "ln_2.bias", kVitW);
+    B.in_proj.N = 3 * kVitW; B.in_proj.K = kVitW;
+    if (const HostParam* p = P.get(b + "attn.in_proj_weight", {3 * kVitW, kVitW})) B.in_proj.W = P.up_T(p->data);
+    B.in_proj.b = P.vec(b + "attn.in_proj_bias", 3 * kVitW);
+    B.out_proj = P.linear(b + "attn.out_proj", kVitW, kVitW, true);
+    B.fc = P.linear(b + "mlp.c_fc", 4 * kVitW, kVitW, true);
+    B.proj = P.linear(b + "mlp.c_proj", kVitW, 4 * kVitW, true);
+  }
+  // ---- bbox MLPs + per-view projection (obj_encoder.py:44-64)
+  for (int vi = 0; vi < 2; ++vi) {
+    const std::string bp = std::string("obj_encoder.bbox_mlp.") + kViews[vi];
+    if (const HostParam* p = P.get(bp + ".0.weight", {768, 4})) h->view[vi].w0 = P.up_f32(p->data.data(), p->data.size());
+    h->view[vi].b0 = P.vec(bp + ".0.bias", 768);
+    h->view[vi].l1 = P.linear(bp + ".3", 768, 768, true);
+    h->view[vi].l2 = P.linear(bp + ".6", 768, 768, true);
+    h->view[vi].pre = P.linear(std::string("obj_encoder.pre_transformer_layer.") + kViews[vi], E, 2 * kVitW, true);
+  }
+  // ---- obs fusion (vima_policy.py:47-49,253-256): Linear(E+2 -> E) on cat(img, ee_emb[ee]) = W[:, :E] img + table[ee]
+  {
+    const HostParam* w = P.get("obs_fusion_layer.weight", {E, E + 2});
+    const HostParam* b = P.get("obs_fusion_layer.bias", {E});
+    const HostParam* ee = P.get("end_effector_encoder.weight", {2, 2});
+    if (w && b && ee) {
+      std::vector<float> wm((size_t)E * E), tab((size_t)2 * E);
+      for (int n = 0; n < E; ++n) {
+        for (int k = 0; k < E; ++k) wm[(size_t)n * E + k] = w->data[(size_t)n * (E + 2) + k];
+        for (int e = 0; e < 2; ++e) {
+          float t = ee->data[e * 2 + 0] * w->data[(size_t)n * (E + 2) + E];
+          t = fmaf(ee->data[e * 2 + 1], w->data[(size_t)n * (E + 2) + E + 1], t);
+          tab[(size_t)e * E + n] = t + b->data[n];
+        }
+      }
+      h->fuse.N = E; h->fuse.K = E;
+      h->fuse.W = P.up_T(wm);
+      h->ee_table = P.up_f32(tab.data(), tab.size());
+    }
+  }
+  // ---- prompt object post MLP (vima_policy.py:103-108)
+  h->pobj[0] = P.linear("prompt_obj_post_layer.0", 768, E, true);
+  h->pobj[1] = P.linear("prompt_obj_post_layer.3", 768, 768, true);
+  h->pobj[2] = P.linear("prompt_obj_post_layer.6", 768, 768, true);
+  // ---- word embedding table (word_embd.py:8-23)
+  if (const HostParam* p = P.get("prompt_embedding._embed_layer.weight", {kVocab, 768}))
+    h->word_table = P.up_f32(p->data.data(), p->data.size());
+  // ---- T5 encoder (prompt_encoder.py; HF T5Attention/T5LayerFF)
+  const std::string t5 = "t5_prompt_encoder.t5.encoder.";
+  for (int l = 0; l < kT5Layers; ++l) {
+    snprintf(buf, sizeof buf, "%sblock.%d.layer.0.", t5.c_str(), l);
+    const std::string a = buf;
+    snprintf(buf, sizeof buf, "%sblock.%d.layer.1.", t5.c_str(), l);
+    const std::string f = buf;
+    auto& L = h->t5[l];
+    L.rms1 = P.vec(a + "layer_norm.weight", kT5Model);
+    L.rms2 = P.vec(f + "layer_norm.weight", kT5Model);
+    const int inner = kT5Heads * kT5D;
+    const HostParam* q = P.get(a + "SelfAttention.q.weight", {inner, kT5Model});
+    const HostParam* k = P.get(a + "SelfAttention.k.weight", {inner, kT5Model});
+    const HostParam* vv = P.get(a + "SelfAttention.v.weight", {inner, kT5Model});
+    if (q && k && vv) {   // fused [q;k;v] -> one GEMM
+      std::vector<float> t;
+      t.reserve((size_t)3 * inner * kT5Model);
+      t.insert(t.end(), q->data.begin(), q->data.end());
+      t.insert(t.end(), k->data.begin(), k->data.end());
+      t.insert(t.end(), vv->data.begin(), vv->data.end());
+      L.qkv.N = 3 * inner; L.qkv.K = kT5Model;
+      L.qkv.W = P.up_T(t);
+    }
+    L.o = P.linear(a + "SelfAttention.o", kT5Model, inner, false);
+    L.wi = P.linear(f + "DenseReluDense.wi", kT5FF, kT5Model, false);
+    L.wo = P.linear(f + "DenseReluDense.wo", kT5Model, kT5FF, false);
+  }
+  if (const HostParam* p = P.get(t5 + "block.0.layer.0.SelfAttention.relative_attention_bias.weight", {kT5Buckets, kT5Heads}))
+    h->t5_relbias_host = p->data;
+  h->t5_final = P.vec(t5 + "final_layer_norm.weight", kT5Model);
+  h->has_t5_post = (E != kT5Model);
+  if (h->has_t5_post) h->t5_post = P.linear("t5_prompt_encoder_post_layer", E, kT5Model, false);
+  // ---- XAttnGPT (xattn_gpt.py:45-68, components.py)
+  if (const HostParam* p = P.get("xattn_gpt.positions_embed.weight", {h->cfg.n_positions, E}))
+    h->pos_emb = P.up_f32(p->data.data(), p->data.size());
+  if (const HostParam* p = P.get("xattn_gpt.xattn_positions_embed.weight", {h->cfg.xattn_n_positions, E}))
+    h->xpos_emb = P.up_f32(p->data.data(), p->data.size());
+  h->dec.resize(NL);
+  for (int i = 0; i < NL; ++i) {
+    auto& D = h->dec[i];
+    snprintf(buf, sizeof buf, "xattn_gpt.xattns.%d.", i);
+    const std::string x = buf;
+    D.xln_g = P.vec(x + "layernorm.weight", E); D.xln_b = P.vec(x + "layernorm.bias", E);
+    D.xln2_g = P.vec(x + "ln.weight", E); D.xln2_b = P.vec(x + "ln.bias", E);
+    D.q = P.linear(x + "query", E, E, false);
+    D.kv = P.linear(x + "key_value", 2 * E, E, false);
+    D.ao = P.linear(x + "attention_out", E, E, false);
+    D.l1 = P.linear(x + "linear1", 4 * E, E, false);
+    D.gate = P.linear(x + "gated_layer", 4 * E, E, false);
+    D.l2 = P.linear(x + "linear2", E, 4 * E, false);
+    snprintf(buf, sizeof buf, "xattn_gpt.h.%d.", i);
+    const std::string b = buf;
+    D.ln1_g = P.vec(b + "ln_1.weight", E); D.ln1_b = P.vec(b + "ln_1.bias", E);
+    D.ln2_g = P.vec(b + "ln_2.weight", E); D.ln2_b = P.vec(b + "ln_2.bias", E);
+    D.c_attn = P.conv1d(b + "attn.c_attn", 3 * E, E);
+    D.c_proj = P.conv1d(b + "attn.c_proj", E, E);
+    D.fc = P.conv1d(b + "mlp.c_fc", 4 * E, E);
+    D.mproj = P.conv1d(b + "mlp.c_proj", E, 4 * E);
+    D.mgate = P.linear(b + "mlp.gated_layer", 4 * E, E, false);
+  }
+  // ---- action decoder: 12 MLPs E->512->512->bins (action_decoder.py:128-166), layer 1 stacked, layer 2 batched
+  {
+    std::vector<float> w1((size_t)kNumHeadsOut * kHeadHidden * E), b1((size_t)kNumHeadsOut * kHeadHidden);
+    std::vector<float> w2((size_t)kNumHeadsOut * kHeadHidden * kHeadHidden), b2((size_t)kNumHeadsOut * kHeadHidden);
+    int hidx = 0;
+    bool ok = true;
+    for (int k = 0; k < 4; ++k) {
+      const int nsub = kActDims[k];
+      for (int j = 0; j < nsub; ++j, ++hidx) {
+        snprintf(buf, sizeof buf, "action_decoder._decoders.%s.mlps.%d", kActKeys[k], j);
+        const std::string m = buf;
+        const HostParam* a = P.get(m + ".0.weight", {kHeadHidden, E});
+        const HostParam* ab = P.get(m + ".0.bias", {kHeadHidden});
+        const HostParam* c = P.get(m + ".3.weight", {kHeadHidden, kHeadHidden});
+        const HostParam* cb = P.get(m + ".3.bias", {kHeadHidden});
+        if (a && ab && c && cb) {
+          memcpy(&w1[(size_t)hidx * kHeadHidden * E], a->data.data(), a->data.size() * 4);
+          memcpy(&b1[(size_t)hidx * kHeadHidden], ab->data.data(), ab->data.size() * 4);
+          memcpy(&w2[(size_t)hidx * kHeadHidden * kHeadHidden], c->data.data(), c->data.size() * 4);
+          memcpy(&b2[(size_t)hidx * kHeadHidden], cb->data.data(), cb->data.size() * 4);
+        } else {
+          ok = false;
+        }
+        h->head3[hidx] = P.linear(m + ".6", kHeadBins[hidx], kHeadHidden, true);
+      }
+    }
+    if (ok) {
+      h->head1.N = kNumHeadsOut * kHeadHidden; h->head1.K = E;
+      h->head1.W = P.up_T(w1); h->head1.b = P.up_f32(b1.data(), b1.size());
+      h->head2_W = P.up_T(w2); h->head2_b = P.up_f32(b2.data(), b2.size());
+    }
+  }
+  // ---- action encoder (action_embd.py): sorted key order == kActKeys order
+  {
+    std::vector<float> w((size_t)4 * 256 * 256), b((size_t)4 * 256);
+    bool ok = true;
+    for (int k = 0; k < 4; ++k) {
+      snprintf(buf, sizeof buf, "action_encoder._embed_dict.%s._layer", kActKeys[k]);
+      const std::string m = buf;
+      const int K = kActDims[k];
+      if (const HostParam* p = P.get(m + ".0.weight", {256, K})) h->act0[k].w0 = P.up_f32(p->data.data(), p->data.size());
+      h->act0[k].b0 = P.vec(m + ".0.bias", 256);
+      const HostParam* c = P.get(m + ".3.weight", {256, 256});
+      const HostParam* cb = P.get(m + ".3.bias", {256});
+      if (c && cb) {
+        memcpy(&w[(size_t)k * 256 * 256], c->data.data(), c->data.size() * 4);
+        memcpy(&b[(size_t)k * 256], cb->data.data(), cb->data.size() * 4);
+      } else {
+        ok = false;
+      }
+    }
+    if (ok) { h->act1_W = P.up_T(w); h->act1_b = P.up_f32(b.data(), b.size()); }
+    h->act_post = P.linear("action_encoder._post_layer", E, 1024, true);
+  }
+  if (!P.missing.empty()) return fail("vima_finalize_params (strict):" + P.missing);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+struct Run {
+  VimaHandle* h;
+  hipStream_t st;
+  int err = 0;
+  void prof_begin(int cls, double flops) {
+    if (!h->prof) return;
+    if (h->ev_used + 2 > h->ev_pool.size()) {
+      for (int i = 0; i < 256; ++i) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        h->ev_pool.push_back(e);
+      }
+    }
+    ProfRec r{cls, h->ev_pool[h->ev_used], h->ev_pool[h->ev_used + 1], flops};
+    h->ev_used += 2;
+    (void)hipEventRecord(r.a, st);
+    h->recs.push_back(r);
+  }
+  void prof_end() {
+    if (!h->prof) return;
+    (void)hipEventRecord(h->recs.back().b, st);
+  }
+  template <typename P> P* ws(size_t n) {   // workspace elements of type P
+    void* p = h->arena.alloc(n * sizeof(P));
+    if (!p && !err) err = fail("workspace allocation failed");
+    return reinterpret_cast<P*>(p);
+  }
+  void* wsT(size_t n) {
+    void* p = h->arena.alloc(n * h->esz());
+    if (!p && !err) err = fail("workspace allocation failed");
+    return p;
+  }
+  void* offT(void* p, long long elems) const { return reinterpret_cast<char*>(p) + elems * (long long)h->esz(); }
+  const void* offT(const void* p, long long elems) const { return reinterpret_cast<const char*>(p) + elems * (long long)h->esz(); }
+
+  int gemm(GemmArgs a) {
+    if (err) return err;
+    prof_begin(0, 2.0 * a.M * (double)a.N * a.K * (a.batch > 0 ? a.batch : 1));
+    int e = launch_gemm(a, h->bf16, st);
+    prof_end();
+    if (e) err = fail(std::string("gemm launch failed: ") + hipGetErrorString((hipError_t)e) + " (M=" + std::to_string(a.M) +
+                      " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + ")", e);
+    return err;
+  }
+  // out = act(A . W^T + b) [* mul] [+ res]
+  int linear(const void* A, int lda, const Lin& L, int M, int act, const void* mul, int ldmul, const float* res, int ldres,
+             float* out32, int ld32, void* outT, int ldT) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = L.W; a.ldw = L.K; a.M = M; a.N = L.N; a.K = L.K;
+    a.bias = L.b; a.act = act; a.mul = mul; a.ldmul = ldmul; a.res = res; a.ldres = ldres;
+    a.out32 = out32; a.ld32 = ld32; a.outT = outT; a.ldT = ldT;
+    return gemm(a);
+  }
+  int ln(const float* in, long long ldin, const float* g, const float* b, float eps, int rms, int rows, int E, float* out32,
+         void* outT) {
+    if (err) return err;
+    prof_begin(2, 0);
+    int e = launch_layernorm(in, ldin, g, b, eps, rms, rows, E, out32, outT, h->bf16, st);
+    prof_end();
+    if (e) err = fail(std::string("layernorm launch failed: ") + hipGetErrorString((hipError_t)e), e);
+    return err;
+  }
+  int other(int e, const char* what) {
+    if (err) return err;
+    if (e) err = fail(std::string(what) + " launch failed: " + hipGetErrorString((hipError_t)e), e);
+    return err;
+  }
+  int attn(const AttnArgs& a, int impl) {
+    if (err) return err;
+    prof_begin(1, 4.0 * a.B * (double)a.H * a.Lq * (double)a.Lk * a.D);
+    int e;
+    if (impl == 1 && h->bf16) e = launch_attn_mfma(a, st);
+    else e = launch_attn_generic(a, h->bf16, st);
+    prof_end();
+    if (e) err = fail(std::string("attention launch failed: ") + hipGetErrorString((hipError_t)e), e);
+    return err;
+  }
+};
+
+#define OTHER(run, call, what)              \
+  do {                                      \
+    (run).prof_begin(2, 0);                 \
+    int e___ = (call);                      \
+    (run).prof_end();                       \
+    (run).other(e___, what);                \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ stages
+// ObjEncoder.forward (obj_encoder.py:66-95). Produces featT [n*2qv, E] (T) and optionally feat32 (fp32).
+int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[2], int n, int qv, float* feat32,
+               void* featT) {
+  VimaHandle* h = R.h;
+  const int E = h->cfg.embed_dim;
+  const int per_view = n * qv;
+  const int M = 2 * per_view;   // internal crop row r = view * per_view + (i*qv + q)
+  if (M == 0) return 0;
+  void* cat = R.wsT((size_t)M * 2 * kVitW);   // [M, 1536] = [vit feature | bbox feature]
+  const int chunk = h->vit_chunk > 0 ? h->vit_chunk : M;
+  const int mc_max = M < chunk ? M : chunk;
+  void* P = R.wsT((size_t)mc_max * 4 * kVitW);
+  float* pre = R.ws<float>((size_t)mc_max * 4 * kVitW);
+  float* x = R.ws<float>((size_t)mc_max * 5 * kVitW);
+  void* hT = R.wsT((size_t)mc_max * 5 * kVitW);
+  void* qkv = R.wsT((size_t)mc_max * 5 * 3 * kVitW);
+  void* att = R.wsT((size_t)mc_max * 5 * kVitW);
+  void* u = R.wsT((size_t)mc_max * 5 * 4 * kVitW);
+  void* y = R.wsT((size_t)mc_max * kVitW);
+  if (R.err) return R.err;
+  for (int r0 = 0; r0 < M; r0 += chunk) {
+    const int mc = (M - r0) < chunk ? (M - r0) : chunk;
+    // patchify, honouring the view boundary inside the chunk
+    for (int vi = 0; vi < 2; ++vi) {
+      const int lo = r0 > vi * per_view ? r0 : vi * per_view;
+      const int hi_ = (r0 + mc) < (vi + 1) * per_view ? (r0 + mc) : (vi + 1) * per_view;
+      if (hi_ > lo)
+        OTHER(R, launch_patchify(crops[vi] + (size_t)(lo - vi * per_view) * 3072, R.offT(P, (long long)(lo - r0) * 4 * kVitW),
+                                 hi_ - lo, h->bf16, R.st), "patchify");
+    }
+    // conv1 as GEMM (vit.py:172), fp32 out
+    R.linear(P, kVitW, h->vit.conv, mc * 4, ACT_NONE, nullptr, 0, nullptr, 0, pre, kVitW, nullptr, 0);
+    OTHER(R, launch_vit_embed(pre, h->vit.cls, h->vit.pos, h->vit.lnpre_g, h->vit.lnpre_b, x, mc, R.st), "vit_embed");
+    const int rows = mc * 5;
+    for (int j = 0; j < kVitLayers; ++j) {
+      auto& B = h->vit.blk[j];
+      R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, hT);
+      R.linear(hT, kVitW, B.in_proj, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * kVitW);
+      R.prof_begin(1, 4.0 * mc * kVitHeads * 25.0 * 32);
+      int e = launch_vit_attn(qkv, att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
+      R.prof_end();
+      R.other(e, "vit_attn");
+      R.linear(att, kVitW, B.out_proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
+      R.ln(x, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, rows, kVitW, nullptr, hT);
+      R.linear(hT, kVitW, B.fc, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, u, 4 * kVitW);
+      R.linear(u, 4 * kVitW, B.proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
+    }
+    // ln_post on the cls rows, then @ projection into cat[:, 0:768]   (vit.py:186-189)
+    R.ln(x, 5 * kVitW, h->vit.lnpost_g, h->vit.lnpost_b, 1e-5f, 0, mc, kVitW, nullptr, y);
+    R.linear(y, kVitW, h->vit.projection, mc, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0,
+             R.offT(cat, (long long)r0 * 2 * kVitW), 2 * kVitW);
+    if (R.err) return R.err;
+  }
+  // bbox MLP per view -> cat[:, 768:1536]; then per-view Linear(1536 -> E) scattered to [n, 2qv, E]
+  void* t1 = R.wsT((size_t)per_view * 768);
+  void* t2 = R.wsT((size_t)per_view * 768);
+  if (R.err) return R.err;
+  for (int vi = 0; vi < 2; ++vi) {
+    OTHER(R, launch_bbox_l1((const long long*)bbox[vi], h->view[vi].w0, h->view[vi].b0, t1, per_view, 768, h->bf16, R.st), "bbox_l1");
+    R.linear(t1, 768, h->view[vi].l1, per_view, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, t2, 768);
+    void* catv = R.offT(cat, (long long)vi * per_view * 2 * kVitW);
+    R.linear(t2, 768, h->view[vi].l2, per_view, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, R.offT(catv, kVitW), 2 * kVitW);
+    GemmArgs a;
+    a.A = catv; a.lda = 2 * kVitW; a.W = h->view[vi].pre.W; a.ldw = 2 * kVitW; a.M = per_view; a.N = E; a.K = 2 * kVitW;
+    a.bias = h->view[vi].pre.b;
+    a.out32 = feat32; a.ld32 = E; a.outT = featT; a.ldT = E;
+    a.rb = qv; a.s_hi = 2 * qv; a.s_lo = 1; a.ro = vi * qv;
+    R.gemm(a);
+  }
+  return R.err;
+}
+
+__global__ void concat_mask_kernel(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int qv) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 2 * qv) return;
+  const int r = i / (2 * qv), c = i % (2 * qv);
+  out[i] = c < qv ? (a[r * qv + c] ? 1 : 0) : (b[r * qv + (c - qv)] ? 1 : 0);
+}
+
+int concat_mask(Run& R, const uint8_t* const mask[2], int n, int qv, uint8_t* out) {
+  if (n * qv == 0) return 0;
+  R.prof_begin(2, 0);
+  hipLaunchKernelGGL(concat_mask_kernel, dim3((n * 2 * qv + 255) / 256), dim3(256), 0, R.st, mask[0], mask[1], out, n, qv);
+  R.prof_end();
+  return R.other((int)hipGetLastError(), "concat_mask");
+}
+
+int t5_bias_table(VimaHandle* h, int L, float** out) {
+  auto it = h->t5_bias_tables.find(L);
+  if (it != h->t5_bias_tables.end()) { *out = it->second; return 0; }
+  const int W = 2 * L - 1;
+  std::vector<float> t((size_t)kT5Heads * W);
+  for (int d = -(L - 1); d <= L - 1; ++d) {
+    const int bkt = t5_bucket(d);
+    for (int hh = 0; hh < kT5Heads; ++hh) t[(size_t)hh * W + d + L - 1] = h->t5_relbias_host[(size_t)bkt * kT5Heads + hh];
+  }
+  float* d = nullptr;
+  HIPCK(hipMalloc((void**)&d, t.size() * 4));
+  h->owned.push_back(d);
+  HIPCK(hipMemcpy(d, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  h->t5_bias_tables[L] = d;
+  *out = d;
+  return 0;
+}
+
+// T5 encoder stack on x fp32 [B*L, 768] (updated in place); result (after final RMSNorm) -> out32 and/or outT
+int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, void* outT) {
+  VimaHandle* h = R.h;
+  const int rows = B * L;
+  float* table = nullptr;
+  if (int e = t5_bias_table(h, L, &table)) return R.err = e;
+  void* hT = R.wsT((size_t)rows * kT5Model);
+  void* qkv = R.wsT((size_t)rows * 3 * kT5Model);
+  void* ctx = R.wsT((size_t)rows * kT5Model);
+  void* u = R.wsT((size_t)rows * kT5FF);
+  if (R.err) return R.err;
+  for (int l = 0; l < kT5Layers; ++l) {
+    auto& Ly = h->t5[l];
+    R.ln(x, kT5Model, Ly.rms1, nullptr, 1e-6f, 1, rows, kT5Model, nullptr, hT);
+    R.linear(hT, kT5Model, Ly.qkv, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * kT5Model);
+    AttnArgs a;
+    a.q = qkv; a.ldq = 3 * kT5Model;
+    a.k = R.offT(qkv, kT5Model); a.ldk = 3 * kT5Model;
+    a.v = R.offT(qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
+    a.out = ctx; a.ldo = kT5Model;
+    a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+    a.mode = ATTN_T5;
+    R.attn(a, h->attn_impl);
+    R.linear(ctx, kT5Model, Ly.o, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
+    R.ln(x, kT5Model, Ly.rms2, nullptr, 1e-6f, 1, rows, kT5Model, nullptr, hT);
+    R.linear(hT, kT5Model, Ly.wi, rows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, u, kT5FF);
+    R.linear(u, kT5FF, Ly.wo, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
+    if (R.err) return R.err;
+  }
+  R.ln(x, kT5Model, h->t5_final, nullptr, 1e-6f, 1, rows, kT5Model, out32, outT);
+  return R.err;
+}
+
+int check_ready(VimaHandle* h) {
+  if (!h) return fail("null handle");
+  if (!h->finalized) return fail("weights not finalized: call vima_set_param for every key, then vima_finalize_params");
+  HIPCK(hipSetDevice(h->device));
+  if (h->arena.reset()) return fail("workspace reset failed");
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int vima_abi_version(void) { return 1; }
+const char* vima_last_error(void) { return g_err.c_str(); }
+int vima_t5_bucket(int rel) { return t5_bucket(rel); }
+
+int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
+  if (!cfg || !out) return fail("vima_create: null argument");
+  const int E = cfg->embed_dim;
+  if (E <= 0 || cfg->xf_n_layers <= 0 || cfg->sattn_n_heads <= 0 || cfg->xattn_n_heads <= 0)
+    return fail("vima_create: non-positive config value");
+  if (E % cfg->sattn_n_heads || E % cfg->xattn_n_heads)   // components.py:120-123 raises ValueError
+    return fail("dim (" + std::to_string(E) + ") must be divisible by num_heads", 22);
+  const int ds = E / cfg->sattn_n_heads, dx = E / cfg->xattn_n_heads;
+  if ((ds != 32 && ds != 64) || (dx != 32 && dx != 64))
+    return fail("vima_create: head dim must be 32 or 64 (got " + std::to_string(ds) + "/" + std::to_string(dx) + ")");
+  if (E % 64 || E > 1024) return fail("vima_create: embed_dim must be a multiple of 64 and <= 1024");
+  if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16) return fail("vima_create: bad precision");
+  if (cfg->n_positions <= 0 || cfg->n_positions > 512 || cfg->xattn_n_positions <= 0) return fail("vima_create: bad table sizes");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail("vima_create: no HIP device available -- this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail("vima_create: bad device index");
+  HIPCK(hipSetDevice(device));
+  VimaHandle* h = new VimaHandle();
+  h->cfg = *cfg;
+  h->device = device;
+  h->bf16 = cfg->precision == VIMA_PRECISION_BF16;
+  *out = h;
+  return 0;
+}
+
+void vima_destroy(VimaHandle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->owned) (void)hipFree(p);
+  h->arena.release();
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int vima_set_param(VimaHandle* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+  if (!h || !name || !data || (ndim > 0 && !shape)) return fail("vima_set_param: null argument");
+  if (h->finalized) return fail("vima_set_param: weights already finalized");
+  HostParam p;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) { p.shape.push_back(shape[i]); n *= shape[i]; }
+  p.data.assign(data, data + n);
+  h->host[name] = std::move(p);
+  return 0;
+}
+
+int vima_finalize_params(VimaHandle* h) {
+  if (!h) return fail("null handle");
+  if (h->finalized) return 0;
+  HIPCK(hipSetDevice(h->device));
+  int e = pack_all(h);
+  if (e) {
+    for (void* p : h->owned) (void)hipFree(p);
+    h->owned.clear();
+    return e;
+  }
+  h->host.clear();
+  h->finalized = true;
+  HIPCK(hipDeviceSynchronize());
+  return 0;
+}
+
+int64_t vima_required_params(const VimaConfig* cfg, char* buf, int64_t buflen) {
+  // host-only: run the packer against an empty staging map and collect the "missing key" names
+  if (!cfg) return -1;
+  VimaHandle tmp;
+  tmp.cfg = *cfg; tmp.bf16 = cfg->precision == VIMA_PRECISION_BF16;
+  std::string saved = g_err;
+  (void)pack_all(&tmp);
+  std::string msg = g_err;
+  g_err = saved;
+  std::string out;
+  size_t pos = 0;
+  const std::string tag = "missing key: ";
+  while ((pos = msg.find(tag, pos)) != std::string::npos) {
+    pos += tag.size();
+    size_t end = msg.find('\n', pos);
+    out += msg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+    out.push_back('\0');
+  }
+  if (buf && buflen >= (int64_t)out.size()) memcpy(buf, out.data(), out.size());
+  return (int64_t)out.size();
+}
+
+int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
+  if (!h || !key) return fail("vima_set_option: null argument");
+  const std::string k = key;
+  if (k == "attn_impl") h->attn_impl = (int)value;
+  else if (k == "gemm_variant") set_gemm_variant((int)value);
+  else if (k == "vit_chunk") h->vit_chunk = (int)value;
+  else return fail("vima_set_option: unknown key " + k);
+  return 0;
+}
+
+int vima_prof_enable(VimaHandle* h, int on) {
+  if (!h) return fail("null handle");
+  h->prof = on != 0;
+  h->recs.clear();
+  h->ev_used = 0;
+  return 0;
+}
+
+int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], double out_flops[3]) {
+  if (!h) return fail("null handle");
+  for (int i = 0; i < 3; ++i) { out_ms[i] = 0; out_launches[i] = 0; out_flops[i] = 0; }
+  for (auto& r : h->recs) {
+    HIPCK(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, r.a, r.b));
+    out_ms[r.cls] += ms;
+    out_launches[r.cls] += 1;
+    out_flops[r.cls] += r.flops;
+  }
+  h->recs.clear();
+  h->ev_used = 0;
+  return 0;
+}
+
+int64_t vima_workspace_bytes(VimaHandle* h) { return h ? (int64_t)h->arena.bytes() : 0; }
+
+int vima_obj_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2], int n, int qv, float* out,
+                    vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  Run R{h, (hipStream_t)stream};
+  void* featT = R.wsT((size_t)n * 2 * qv * h->cfg.embed_dim);
+  if (R.err) return R.err;
+  return obj_encode(R, crops, bbox, n, qv, out, featT);
+}
+
+int vima_obs_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2],
+                    const uint8_t* const mask[2], const int64_t* ee, int n, int qv, float* out_tokens, uint8_t* out_mask,
+                    vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  Run R{h, (hipStream_t)stream};
+  const int E = h->cfg.embed_dim;
+  const int rows = n * 2 * qv;
+  if (rows == 0) return 0;
+  void* featT = R.wsT((size_t)rows * E);
+  if (R.err) return R.err;
+  if (obj_encode(R, crops, bbox, n, qv, nullptr, featT)) return R.err;
+  // obs_fusion_layer on cat(img_feats, ee_feats) (vima_policy.py:253-256)
+  R.linear(featT, E, h->fuse, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
+  OTHER(R, launch_add_row_table(out_tokens, rows, E, h->ee_table, (const long long*)ee, 2 * qv, R.st), "ee_table");
+  concat_mask(R, mask, n, qv, out_mask);
+  return R.err;
+}
+
+int vima_t5_encode(VimaHandle* h, const float* x, const uint8_t* mask, int B, int L, float* out, vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  Run R{h, (hipStream_t)stream};
+  const size_t n = (size_t)B * L * kT5Model;
+  float* xw = R.ws<float>(n);
+  if (R.err) return R.err;
+  HIPCK(hipMemcpyAsync(xw, x, n * 4, hipMemcpyDeviceToDevice, R.st));
+  return t5_stack(R, xw, mask, B, L, out, nullptr);
+}
+
+int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, const uint8_t* const crops[2],
+                       const int64_t* const bbox[2], const uint8_t* const mask[2], int n_img, int qv,
+                       const int32_t* tok_src, int B, int Lp, float* out_tokens, uint8_t* out_mask, vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  (void)n_words;
+  Run R{h, (hipStream_t)stream};
+  const int E = h->cfg.embed_dim;
+  const int orows = n_img * 2 * qv;
+  float* objtok = R.ws<float>((size_t)(orows > 0 ? orows : 1) * 768);
+  uint8_t* objmask = R.ws<uint8_t>((size_t)(orows > 0 ? orows : 1));
+  if (R.err) return R.err;
+  if (orows > 0) {
+    void* featT = R.wsT((size_t)orows * E);
+    void* p1 = R.wsT((size_t)orows * 768);
+    void* p2 = R.wsT((size_t)orows * 768);
+    if (R.err) return R.err;
+    if (obj_encode(R, crops, bbox, n_img, qv, nullptr, featT)) return R.err;
+    // prompt_obj_post_layer (vima_policy.py:165)
+    R.linear(featT, E, h->pobj[0], orows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, p1, 768);
+    R.linear(p1, 768, h->pobj[1], orows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, p2, 768);
+    R.linear(p2, 768, h->pobj[2], orows, ACT_NONE, nullptr, 0, nullptr, 0, objtok, 768, nullptr, 0);
+    concat_mask(R, mask, n_img, qv, objmask);
+  }
+  const int rows = B * Lp;
+  float* x = R.ws<float>((size_t)rows * 768);
+  if (R.err) return R.err;
+  OTHER(R, launch_prompt_assemble(tok_src, (const long long*)word_ids, h->word_table, objtok, objmask, x, out_mask, rows, 768, R.st),
+        "prompt_assemble");
+  if (!h->has_t5_post) return t5_stack(R, x, out_mask, B, Lp, out_tokens, nullptr);
+  void* yT = R.wsT((size_t)rows * 768);
+  if (R.err) return R.err;
+  if (t5_stack(R, x, out_mask, B, Lp, nullptr, yT)) return R.err;
+  return R.linear(yT, 768, h->t5_post, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
+}
+
+int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
+                int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
+                float* out, vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  const int E = h->cfg.embed_dim;
+  if (T <= 0 || B <= 0 || Q <= 0) return fail("vima_decode: empty input");
+  if (L_act < 0 || L_act > T || (L_act > 0 && !act_tok) || L_act < T - 1) return fail("vima_decode: L_act must be T-1 or T");
+  const int Lq = T * Q + L_act;
+  if (Lq > h->cfg.n_positions) return fail("vima_decode: history longer than n_positions", 34);
+  if (Lp > h->cfg.xattn_n_positions)   // xattn_gpt.py:110 assert
+    return fail("AssertionError: prompt_tokens.size(1) <= xattn_n_positions (" + std::to_string(Lp) + " > " +
+                std::to_string(h->cfg.xattn_n_positions) + ")", 33);
+  Run R{h, (hipStream_t)stream};
+  const int rq = B * Lq, rp = B * Lp;
+  const int Hx = h->cfg.xattn_n_heads, Hs = h->cfg.sattn_n_heads;
+  float* x32 = R.ws<float>((size_t)rq * E);
+  void* xT = R.wsT((size_t)rq * E);
+  uint8_t* dmask = R.ws<uint8_t>((size_t)rq);
+  void* pT = R.wsT((size_t)rp * E);
+  void* qn = R.wsT((size_t)rq * E);
+  void* Qb = R.wsT((size_t)rq * E);
+  void* KV = R.wsT((size_t)rp * 2 * E);
+  void* ctx = R.wsT((size_t)rq * E);
+  float* a32 = R.ws<float>((size_t)rq * E);
+  void* aT = R.wsT((size_t)rq * E);
+  void* g = R.wsT((size_t)rq * 4 * E);
+  void* u = R.wsT((size_t)rq * 4 * E);
+  void* qkv = R.wsT((size_t)rq * 3 * E);
+  float* n32 = R.ws<float>((size_t)rq * E);
+  void* nT = R.wsT((size_t)rq * E);
+  if (R.err) return R.err;
+  OTHER(R, launch_dec_embed(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, dmask, T, B, Q, L_act, E,
+                            h->bf16, R.st), "dec_embed");
+  OTHER(R, launch_prompt_pos(prompt, stride_b, stride_l, prompt_mask, h->xpos_emb, h->cfg.xattn_n_positions, pT, B, Lp, E,
+                             h->bf16, R.st), "prompt_pos");
+  for (int i = 0; i < h->cfg.xf_n_layers; ++i) {
+    auto& D = h->dec[i];
+    // ---- XAttention.forward (components.py:158-228)
+    R.ln(x32, E, D.xln_g, D.xln_b, 1e-5f, 0, rq, E, nullptr, qn);
+    R.linear(qn, E, D.q, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, Qb, E);
+    R.linear(pT, E, D.kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+    AttnArgs a;
+    a.q = Qb; a.ldq = E; a.k = KV; a.ldk = 2 * E; a.v = R.offT(KV, E); a.ldv = 2 * E; a.out = ctx; a.ldo = E;
+    a.kmask = prompt_mask; a.B = B; a.H = Hx; a.Lq = Lq; a.Lk = Lp; a.D = E / Hx;
+    a.scale = 1.0f / sqrtf((float)(E / Hx)); a.mode = ATTN_CROSS;
+    R.attn(a, h->attn_impl);
+    R.linear(ctx, E, D.ao, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, aT, E);            // + q residual
+    R.ln(a32, E, D.xln2_g, D.xln2_b, 1e-5f, 0, rq, E, nullptr, qn);
+    R.linear(aT, E, D.gate, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, g, 4 * E);  // gate reads the UN-normed stream
+    R.linear(qn, E, D.l1, rq, ACT_GELU, g, 4 * E, nullptr, 0, nullptr, 0, u, 4 * E);
+    R.linear(u, 4 * E, D.l2, rq, ACT_NONE, nullptr, 0, a32, E, x32, E, xT, E);
+    // ---- Block.forward (components.py:23-37), post-LN
+    R.linear(xT, E, D.c_attn, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * E);
+    AttnArgs s;
+    s.q = qkv; s.ldq = 3 * E; s.k = R.offT(qkv, E); s.ldk = 3 * E; s.v = R.offT(qkv, 2 * E); s.ldv = 3 * E; s.out = ctx; s.ldo = E;
+    s.kmask = dmask; s.B = B; s.H = Hs; s.Lq = Lq; s.Lk = Lq; s.D = E / Hs;
+    s.scale = 1.0f / sqrtf((float)(E / Hs)); s.mode = ATTN_CAUSAL;
+    R.attn(s, h->attn_impl);
+    R.linear(ctx, E, D.c_proj, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, nullptr, 0);   // x + a
+    R.ln(a32, E, D.ln1_g, D.ln1_b, 1e-5f, 0, rq, E, n32, nT);                           // n = ln_1(x + a)
+    R.linear(nT, E, D.mgate, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, g, 4 * E);
+    R.linear(nT, E, D.fc, rq, ACT_GELU, g, 4 * E, nullptr, 0, nullptr, 0, u, 4 * E);
+    R.linear(u, 4 * E, D.mproj, rq, ACT_NONE, nullptr, 0, n32, E, a32, E, nullptr, 0);  // n + m
+    R.ln(a32, E, D.ln2_g, D.ln2_b, 1e-5f, 0, rq, E, x32, xT);                           // h = ln_2(n + m)
+    if (R.err) return R.err;
+  }
+  OTHER(R, launch_gather_pred(x32, out, T, B, Q, Lq, E, R.st), "gather_pred");
+  return R.err;
+}
+
+int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logits, vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  if (Rn <= 0) return 0;
+  Run R{h, (hipStream_t)stream};
+  const int E = h->cfg.embed_dim;
+  const int HH = kNumHeadsOut * kHeadHidden;
+  void* tT = R.wsT((size_t)Rn * E);
+  void* h1 = R.wsT((size_t)Rn * HH);
+  void* h2 = R.wsT((size_t)Rn * HH);
+  if (R.err) return R.err;
+  OTHER(R, launch_cast(tokens, tT, (long long)Rn * E, h->bf16, R.st), "cast");
+  R.linear(tT, E, h->head1, Rn, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, h1, HH);
+  GemmArgs a;   // 12 independent 512x512 layers as one batched launch
+  a.A = h1; a.lda = HH; a.bsA = kHeadHidden; a.W = h->head2_W; a.ldw = kHeadHidden; a.bsW = (long long)kHeadHidden * kHeadHidden;
+  a.M = Rn; a.N = kHeadHidden; a.K = kHeadHidden; a.batch = kNumHeadsOut; a.bias = h->head2_b; a.bsBias = kHeadHidden;
+  a.act = ACT_RELU; a.outT = h2; a.ldT = HH; a.bsT = kHeadHidden;
+  R.gemm(a);
+  int col = 0;
+  for (int j = 0; j < kNumHeadsOut; ++j) {
+    GemmArgs b;
+    b.A = R.offT(h2, (long long)j * kHeadHidden); b.lda = HH; b.W = h->head3[j].W; b.ldw = kHeadHidden;
+    b.M = Rn; b.N = kHeadBins[j]; b.K = kHeadHidden; b.bias = h->head3[j].b;
+    b.out32 = out_logits + col; b.ld32 = kLogits;
+    R.gemm(b);
+    col += kHeadBins[j];
+  }
+  return R.err;
+}
+
+int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int Rn, float* out, vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  if (Rn <= 0) return 0;
+  Run R{h, (hipStream_t)stream};
+  const int E = h->cfg.embed_dim;
+  void* t1 = R.wsT((size_t)Rn * 1024);
+  void* t2 = R.wsT((size_t)Rn * 1024);
+  if (R.err) return R.err;
+  for (int k = 0; k < 4; ++k)
+    OTHER(R, launch_action_l1((const long long*)idx[k], kActDims[k], h->act0[k].w0, h->act0[k].b0, t1, Rn, 1024, k * 256, h->bf16, R.st),
+          "action_l1");
+  GemmArgs a;
+  a.A = t1; a.lda = 1024; a.bsA = 256; a.W = h->act1_W; a.ldw = 256; a.bsW = 256 * 256; a.M = Rn; a.N = 256; a.K = 256; a.batch = 4;
+  a.bias = h->act1_b; a.bsBias = 256; a.outT = t2; a.ldT = 1024; a.bsT = 256;
+  R.gemm(a);
+  return R.linear(t2, 1024, h->act_post, Rn, ACT_NONE, nullptr, 0, nullptr, 0, out, E, nullptr, 0);
+}
+
+// ---------------------------------------------------------------------------------------------- operator-level
+int vima_op_linear(VimaHandle* h, const float* A, const float* W, const float* bias, const float* mul, const float* res, int M,
+                   int N, int K, int act, float* out, vima_stream_t stream) {
+  if (!h) return fail("null handle");
+  HIPCK(hipSetDevice(h->device));
+  if (h->arena.reset()) return fail("workspace reset failed");
+  Run R{h, (hipStream_t)stream};
+  void* aT = R.wsT((size_t)M * K);
+  void* wT = R.wsT((size_t)N * K);
+  void* mT = mul ? R.wsT((size_t)M * N) : nullptr;
+  if (R.err) return R.err;
+  if ((long long)M * K % 4 || (long long)N * K % 4 || (mul && (long long)M * N % 4)) return fail("vima_op_linear: sizes must be multiples of 4");
+  OTHER(R, launch_cast(A, aT, (long long)M * K, h->bf16, R.st), "cast");
+  OTHER(R, launch_cast(W, wT, (long long)N * K, h->bf16, R.st), "cast");
+  if (mul) OTHER(R, launch_cast(mul, mT, (long long)M * N, h->bf16, R.st), "cast");
+  GemmArgs a;
+  a.A = aT; a.lda = K; a.W = wT; a.ldw = K; a.M = M; a.N = N; a.K = K; a.bias = bias; a.act = act; a.mul = mT; a.ldmul = N;
+  a.res = res; a.ldres = N; a.out32 = out; a.ld32 = N;
+  return R.gemm(a);
+}
+
+int vima_op_layernorm(VimaHandle* h, const float* x, const float* gamma, const float* beta, float eps, int rms, int rows, int E,
+                      float* out, vima_stream_t stream) {
+  if (!h) return fail("null handle");
+  HIPCK(hipSetDevice(h->device));
+  Run R{h, (hipStream_t)stream};
+  return R.ln(x, E, gamma, beta, eps, rms, rows, E, out, nullptr);
+}
+
+__global__ void widen_kernel(const bf16_t* in, float* out, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = bf16_to_f32(in[i]);
+}
+
+int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float* v, const uint8_t* kmask, const float* relbias,
+                      int B, int H, int Lq, int Lk, int D, float scale, int mode, int impl, float* out, vima_stream_t stream) {
+  if (!h) return fail("null handle");
+  HIPCK(hipSetDevice(h->device));
+  if (h->arena.reset()) return fail("workspace reset failed");
+  Run R{h, (hipStream_t)stream};
+  const long long nq = (long long)B * Lq * H * D, nk = (long long)B * Lk * H * D;
+  void* qT = R.wsT(nq); void* kT = R.wsT(nk); void* vT = R.wsT(nk); void* oT = R.wsT(nq);
+  if (R.err) return R.err;
+  OTHER(R, launch_cast(q, qT, nq, h->bf16, R.st), "cast");
+  OTHER(R, launch_cast(k, kT, nk, h->bf16, R.st), "cast");
+  OTHER(R, launch_cast(v, vT, nk, h->bf16, R.st), "cast");
+  AttnArgs a;
+  a.q = qT; a.ldq = H * D; a.k = kT; a.ldk = H * D; a.v = vT; a.ldv = H * D; a.out = oT; a.ldo = H * D;
+  a.kmask = kmask; a.relbias = relbias; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale; a.mode = mode;
+  if (impl == 1 && !h->bf16) return fail("vima_op_attention: the MFMA kernel needs bf16 precision");
+  if (R.attn(a, impl)) return R.err;
+  if (h->bf16) {
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, R.st, (const bf16_t*)oT, out, nq);
+    return R.other((int)hipGetLastError(), "widen");
+  }
+  HIPCK(hipMemcpyAsync(out, oT, nq * 4, hipMemcpyDeviceToDevice, R.st));
+  return 0;
+}
+
+}  // extern "C"
