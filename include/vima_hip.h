@@ -123,7 +123,8 @@ int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float
 int vima_t5_bucket(int relative_position);
 
 /* ---- tuning / instrumentation ---------------------------------------------------------------------------------- */
-/* key in {"attn_impl" (0 generic, 1 mfma), "gemm_variant" (0 builtin LDS-DMA, 1 asm LDS-DMA), "vit_chunk" (crops)} */
+/* key in {"attn_impl" (0 generic, 1 mfma), "gemm_variant" (0 builtin LDS-DMA, 1 asm LDS-DMA),
+ *         "gemm_tile" (0 auto, 1 128x128, 2 256x256), "vit_chunk" (crops)} */
 int vima_set_option(VimaHandle* h, const char* key, int64_t value);
 /* When enabled every kernel launch is bracketed by HIP events on the launch stream and attributed to a class:
  * 0 = GEMM, 1 = attention, 2 = other. vima_prof_read synchronises and returns per class

@@ -196,10 +196,12 @@ def test_policy(name, prec, attn_impl=1, gemm_variant=1):
     del pol
 
 
-def bench_gemm(pol, variant):
+def bench_gemm(pol, variant, tile=0):
     lib = pol._lib
     pol.set_option("gemm_variant", variant)
-    for (M, N, K) in [(32768, 2304, 768), (32768, 768, 3072), (131072, 1536, 768), (2048, 768, 768)]:
+    pol.set_option("gemm_tile", tile)
+    for (M, N, K) in [(131072, 2304, 768), (131072, 3072, 768), (131072, 768, 3072), (131072, 768, 768), (81920, 2304, 768),
+                      (81920, 3072, 768), (131072, 1536, 768), (2048, 768, 768)]:
         A = torch.randn(M, K, device="cuda")
         W = torch.randn(N, K, device="cuda") * 0.03
         out = torch.empty(M, N, device="cuda")
@@ -212,7 +214,7 @@ def bench_gemm(pol, variant):
         pr = pol.prof_read()
         pol.prof_enable(False)
         ms = pr["gemm"]["ms"] / max(pr["gemm"]["launches"], 1)
-        log(f"  gemm-perf[{pol.precision},v{variant}] M{M} N{N} K{K}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s (fp32-out epilogue)")
+        log(f"  gemm-perf[{pol.precision},v{variant},tile{tile}] M{M} N{N} K{K}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s (fp32-out epilogue)")
 
 
 def main():
@@ -239,11 +241,9 @@ def main():
     if "perf" in steps:
         try:
             pol = mk_policy("bf16")
-            for variant in (1, 0):
-                bench_gemm(pol, variant)
+            for tile in (1, 2):
+                bench_gemm(pol, 1, tile)
             del pol
-            pol = mk_policy("fp32")
-            bench_gemm(pol, 1)
         except Exception:
             log("EXC in perf", traceback.format_exc())
     log("done")

@@ -162,9 +162,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
 // V^T comes from a transposed LDS image of the V tile (rows padded to 72 B: conflict-free ds_read_b64).
 constexpr int VT_STRIDE = 36;  // bf16 elements per Vt row (32 keys + 4 pad)
 
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack2_bf16(a, b); }
 
 template <int D, int MODE>
 __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {

@@ -16,12 +16,13 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even; lowers to the gfx950 hardware conversion (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {   // low half = a
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -52,8 +53,8 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
 __device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
   uint2 u;
-  u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-  u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  u.x = pack2_bf16(v.x, v.y);
+  u.y = pack2_bf16(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = u;
 }
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_RELU: return fmaxf(v, 0.0f);
     case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact erf GELU (nn.GELU())
-    case ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));                   // x * sigmoid(1.702 x)
+    case ACT_QUICKGELU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));          // x * sigmoid(1.702 x), v_exp + v_rcp
     default: return v;
   }
 }

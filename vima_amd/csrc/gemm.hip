@@ -5,19 +5,23 @@
 // T5DenseActDense wi/wo, nn/utils.py build_mlp Linear layers).
 //
 // Design (CDNA4, wave64):
-//  * 128x128 output tile per 256-thread workgroup (4 waves as 2(m) x 2(n), 64x64 per wave = 2x2 MFMA 32x32 tiles).
+//  * Two tile shapes from one template:
+//      TileS 128x128, 4 waves (2x2, 64x64 per wave),  64 KiB LDS -> 2 workgroups/CU  (small / skinny problems, fp32 mode)
+//      TileL 256x256, 8 waves (2x4, 128x64 per wave), 128 KiB LDS -> 1 workgroup/CU  (the big bf16 GEMMs: half the
+//            LDS and L2 bytes per FLOP of TileS, 8 MFMAs per 6 ds_read_b128)
 //  * K is consumed in 128-BYTE row slices (64 bf16 / 32 fp32): each tile row is 8 x 16 B chunks.
 //  * global -> LDS with `global_load_lds_dwordx4` (no VGPR round trip). The LDS image is lane-linear, so the
 //    bank-conflict swizzle is applied on the SOURCE address: LDS slot (row r, position p) receives global chunk
 //    c = p ^ ((r >> 1) & 7); fragments are read back with ds_read_b128 at position c ^ ((r >> 1) & 7).
 //    With 128-B rows every 16-lane ds_read_b128 group then touches 16 distinct 16-B slots of the 256-B bank row.
-//  * 2 LDS stages (2 x 32 KiB); the next K-slice is issued before the MFMAs of the current one and waited for
-//    with ONE `s_waitcnt vmcnt(0)` + `s_barrier` per K-slice (2 workgroups/CU hide the rest).
+//  * 2 LDS stages; the LDS-DMA of slice k+1 is issued (inline asm, hidden from hipcc's waitcnt bookkeeping so it is
+//    NOT drained in front of the ds_reads) while slice k is multiplied; fragments of step kk+1 are prefetched into a
+//    second register set while the MFMAs of step kk run; ONE `s_waitcnt vmcnt(0)` + `s_barrier` per K-slice.
 //  * operands are fed SWAPPED to the matrix core (W fragment as A-operand, activation fragment as B-operand) so a
 //    lane ends up holding 4 CONSECUTIVE output columns of one output row -> 8/16-byte vector epilogue
 //    (bias / activation / GEGLU gate multiply / residual / dual fp32+bf16 store) instead of scalar stores.
 //  * blockIdx -> tile mapping is XCD-aware: consecutive workgroups on one XCD (blockIdx % 8) walk the n-tiles of
-//    the same 128-row A panel, so the panel is fetched from HBM once per XCD L2.
+//    the same A row panel, so the panel is fetched from HBM once per XCD L2.
 #include "kernels.h"
 #include <stdlib.h>
 
@@ -25,12 +29,23 @@ namespace vima {
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
 constexpr int ROW_BYTES = 128;                 // bytes of K per tile row
-constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A tile + W tile
-constexpr int NSTAGE = 2;
-constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct Tile {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int NW = WM * WN;             // waves
+  static constexpr int THREADS = NW * 64;
+  static constexpr int MI = BM / WM / 32;        // 32x32 MFMA tiles per wave along m
+  static constexpr int NI = BN / WN / 32;        // ... along n
+  static constexpr int PA = BM / 8 / NW;         // 1-KiB LDS-DMA pieces (8 rows) per wave for the A tile
+  static constexpr int PW = BN / 8 / NW;
+  static constexpr int A_BYTES = BM * ROW_BYTES;
+  static constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+  static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+};
+using TileS = Tile<128, 128, 2, 2>;
+using TileL = Tile<256, 256, 2, 4>;
 
 template <typename T> struct KCfg;
 template <> struct KCfg<bf16_t> { static constexpr int BK = 64; static constexpr int EPC = 8; };  // elems / 16-B chunk
@@ -102,16 +117,16 @@ struct GemmDev {
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
   int mtiles, ntiles;
-  int vec_ok;   // all pointers/strides allow 4-wide vector epilogue
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
-template <typename T, int ACT, bool VEC, bool ASMLDS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev p) {
+template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS>
+__global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = KCfg<T>::BK;
   constexpr int EPC = KCfg<T>::EPC;
   constexpr int KSTEPS = BK / 16;
+  constexpr int MI = TL::MI, NI = TL::NI, NW = TL::NW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -127,102 +142,119 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev p) {
   const int tm = (idx / p.ntiles) * 8 + xcd;
   if (tm >= p.mtiles) return;
   const int z = blockIdx.y;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TL::BM, n0 = tn * TL::BN;
 
   const T* A = reinterpret_cast<const T*>(p.A) + (long long)z * p.bsA;
   const T* W = reinterpret_cast<const T*>(p.W) + (long long)z * p.bsW;
 
-  // per-lane source pointers of the 4 (A) + 4 (W) LDS-DMA pieces of one K-slice
-  const T* srcA[4];
-  const T* srcW[4];
+  // per-lane source pointers of this wave's LDS-DMA pieces of one K-slice (piece = 8 tile rows = 1 KiB)
+  const T* srcA[TL::PA];
+  const T* srcW[TL::PW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int s = (i * 4 + w) * 64 + lane;
+  for (int i = 0; i < TL::PA; ++i) {
+    const int s = (i * NW + w) * 64 + lane;
     const int r = s >> 3, pp = s & 7;
     const int c = pp ^ ((r >> 1) & 7);
     int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
-    int rw = n0 + r; rw = rw < p.N ? rw : p.N - 1;
     srcA[i] = A + (long long)ra * p.lda + c * EPC;
+  }
+#pragma unroll
+  for (int i = 0; i < TL::PW; ++i) {
+    const int s = (i * NW + w) * 64 + lane;
+    const int r = s >> 3, pp = s & 7;
+    const int c = pp ^ ((r >> 1) & 7);
+    int rw = n0 + r; rw = rw < p.N ? rw : p.N - 1;
     srcW[i] = W + (long long)rw * p.ldw + c * EPC;
   }
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / TL::WN, wn = w % TL::WN;
+  const int arow = wm * (MI * 32) + l31;   // + mi*32
+  const int wrow = wn * (NI * 32) + l31;   // + ni*32
   const int nk = p.K / BK;
-
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  auto issue = [&](int stage, int kt) {
-    if constexpr (ASMLDS) {
-      const unsigned sA = smem_base + stage * STAGE_BYTES + w * 1024;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        glds16_asm(srcA[i] + kt * BK, sA + i * 4096);
-        glds16_asm(srcW[i] + kt * BK, sA + TILE_BYTES + i * 4096);
-      }
-    } else {
-      char* sA = smem + stage * STAGE_BYTES;
-      char* sW = sA + TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        glds16(srcA[i] + kt * BK, sA + (i * 4 + w) * 1024);
-        glds16(srcW[i] + kt * BK, sW + (i * 4 + w) * 1024);
-      }
-    }
+
+  // one 1-KiB LDS-DMA piece j of K-slice kt into `stage` (j < PA: A tile rows, else W tile rows)
+  constexpr int NP = TL::PA + TL::PW;
+  auto issue_piece = [&](int stage, int kt, int j) {
+    const int i = j < TL::PA ? j : j - TL::PA;
+    const int off = stage * TL::STAGE_BYTES + (j < TL::PA ? 0 : TL::A_BYTES) + (i * NW + w) * 1024;
+    const T* src = (j < TL::PA ? srcA[i] : srcW[i]) + kt * BK;
+    if constexpr (ASMLDS) glds16_asm(src, smem_base + off);
+    else glds16(src, smem + off);
   };
 
-  issue(0, 0);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) issue_piece(0, 0, j);
   wait_all_and_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
-    const char* sA = smem + cur * STAGE_BYTES;
-    const char* sW = sA + TILE_BYTES;
+    const bool more = kt + 1 < nk;
+    const char* sA = smem + cur * TL::STAGE_BYTES;
+    const char* sW = sA + TL::A_BYTES;
+    Frag<T> fa[2][MI], fw[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fa[0][mi].load(sA, arow + mi * 32, 0, hi);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fw[0][ni].load(sW, wrow + ni * 32, 0, hi);
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
-      Frag<T> fa[2], fw[2];
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < KSTEPS) {   // prefetch the next step's fragments while this step's MFMAs run
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) fa[mi].load(sA, wm * 64 + mi * 32 + l31, kk, hi);
+        for (int mi = 0; mi < MI; ++mi) fa[nb][mi].load(sA, arow + mi * 32, kk + 1, hi);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) fw[ni].load(sW, wn * 64 + ni * 32 + l31, kk, hi);
+        for (int ni = 0; ni < NI; ++ni) fw[nb][ni].load(sW, wrow + ni * 32, kk + 1, hi);
+      }
+      // this step's share of the next K-slice's LDS-DMA (spread over the steps: the first MFMAs after the barrier
+      // wait only for LDS latency, not for a burst of 8 VMEM issues)
+      if (more) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int j = kk * NP / KSTEPS; j < (kk + 1) * NP / KSTEPS; ++j) issue_piece(cur ^ 1, kt + 1, j);
+      }
+      // pin the order: [ds_reads of step kk+1, DMA issue] then [MFMAs of step kk]; without this hipcc re-serialises
+      // read -> wait -> 2 MFMAs on one register set and the LDS latency is exposed
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mma(fw[ni], fa[mi], acc[mi][ni]);
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     wait_all_and_barrier();
   }
 
   // ------------------------------------------------------------------ epilogue
-  // acc[mi][ni][4q+e] = C[m = m0 + wm*64 + mi*32 + l31][n = n0 + wn*64 + ni*32 + 8q + 4hi + e]
+  // acc[mi][ni][4q+e] = C[m = m0 + wm*MI*32 + mi*32 + l31][n = n0 + wn*NI*32 + ni*32 + 8q + 4hi + e]
   const float* bias = p.bias ? p.bias + (long long)z * p.bsBias : nullptr;
   const T* mul = p.mul ? reinterpret_cast<const T*>(p.mul) + (long long)z * p.bsMul : nullptr;
   const float* res = p.res ? p.res + (long long)z * p.bsRes : nullptr;
   float* out32 = p.out32 ? p.out32 + (long long)z * p.bs32 : nullptr;
   T* outT = p.outT ? reinterpret_cast<T*>(p.outT) + (long long)z * p.bsT : nullptr;
+  const int act = ACT >= 0 ? ACT : p.act;
 
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + l31;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wm * (MI * 32) + mi * 32 + l31;
     if (m >= p.M) continue;
     long long orow = m;
     if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
+        const int n = n0 + wn * (NI * 32) + ni * 32 + 8 * q + 4 * hi;
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
-        const int act = ACT >= 0 ? ACT : p.act;
         if constexpr (VEC) {   // N % 4 == 0 => n + 3 < N
           if (bias) { const float4 b = load4(bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
           if (act != ACT_NONE) {
@@ -253,17 +285,52 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev p) {
   }
 }
 
-// 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin. Override with VIMA_GEMM_VARIANT for A/B runs.
+// 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin (TileS only). Override with VIMA_GEMM_VARIANT.
 int g_gemm_variant = -1;
+int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL (bf16 only)
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
 inline int gemm_variant() {
-  if (g_gemm_variant < 0) {
-    const char* e = getenv("VIMA_GEMM_VARIANT");
-    g_gemm_variant = (e && e[0] == '0') ? 0 : 1;
-  }
+  if (g_gemm_variant < 0) g_gemm_variant = env_int("VIMA_GEMM_VARIANT", 1) ? 1 : 0;
   return g_gemm_variant;
+}
+inline int gemm_tile() {
+  if (g_gemm_tile < 0) g_gemm_tile = env_int("VIMA_GEMM_TILE", 0);
+  return g_gemm_tile;
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS>
+int launch_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TL, ACT, VEC, ASMLDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, TL, ACT, VEC, ASMLDS>), grid, dim3(TL::THREADS), TL::SMEM_BYTES, st, d);
+  return (int)hipGetLastError();
+}
+
+template <typename T, typename TL, bool ASMLDS>
+int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
+  d.mtiles = (a.M + TL::BM - 1) / TL::BM;
+  d.ntiles = (a.N + TL::BN - 1) / TL::BN;
+  const int groups = (d.mtiles + 7) / 8;
+  dim3 grid((unsigned)(groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  if (!vec) return launch_inst<T, TL, -1, false, ASMLDS>(d, grid, st);
+  switch (a.act) {
+    case ACT_NONE: return launch_inst<T, TL, ACT_NONE, true, ASMLDS>(d, grid, st);
+    case ACT_RELU: return launch_inst<T, TL, ACT_RELU, true, ASMLDS>(d, grid, st);
+    case ACT_GELU: return launch_inst<T, TL, ACT_GELU, true, ASMLDS>(d, grid, st);
+    case ACT_QUICKGELU: return launch_inst<T, TL, ACT_QUICKGELU, true, ASMLDS>(d, grid, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
 
 template <typename T>
 int launch_t(const GemmArgs& a, hipStream_t st) {
@@ -281,31 +348,24 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
-  d.mtiles = (a.M + BM - 1) / BM;
-  d.ntiles = (a.N + BN - 1) / BN;
+  d.mtiles = d.ntiles = 0;
   bool v = (a.N % 4 == 0);
   if (a.bias) v = v && aligned_to(a.bias, 16) && (a.bsBias % 4 == 0);
   if (a.mul) v = v && aligned_to(a.mul, 4 * es) && (a.ldmul % 4 == 0) && (a.bsMul % 4 == 0);
   if (a.res) v = v && aligned_to(a.res, 16) && (a.ldres % 4 == 0) && (a.bsRes % 4 == 0);
   if (a.out32) v = v && aligned_to(a.out32, 16) && (a.ld32 % 4 == 0) && (a.bs32 % 4 == 0);
   if (a.outT) v = v && aligned_to(a.outT, 4 * es) && (a.ldT % 4 == 0) && (a.bsT % 4 == 0);
-  d.vec_ok = v ? 1 : 0;
-  const int groups = (d.mtiles + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
-  const bool asmlds = gemm_variant() == 1;
-#define VIMA_GEMM_LAUNCH(ACT_, VEC_)                                                                       \
-  do {                                                                                                     \
-    if (asmlds) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, true>), grid, dim3(256), SMEM_BYTES, st, d); \
-    else hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, false>), grid, dim3(256), SMEM_BYTES, st, d);       \
-  } while (0)
-  if (!v) VIMA_GEMM_LAUNCH(-1, false);
-  else if (a.act == ACT_NONE) VIMA_GEMM_LAUNCH(ACT_NONE, true);
-  else if (a.act == ACT_RELU) VIMA_GEMM_LAUNCH(ACT_RELU, true);
-  else if (a.act == ACT_GELU) VIMA_GEMM_LAUNCH(ACT_GELU, true);
-  else if (a.act == ACT_QUICKGELU) VIMA_GEMM_LAUNCH(ACT_QUICKGELU, true);
-  else return (int)hipErrorInvalidValue;
-#undef VIMA_GEMM_LAUNCH
-  return (int)hipGetLastError();
+  if constexpr (sizeof(T) == 2) {
+    // TileL when the 256x256 grid still fills the chip (>= ~1 workgroup per CU) and padding waste is small
+    const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
+    const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
+    bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 224) && waste < 1.15;
+    if (gemm_tile() == 1) large = false;
+    if (gemm_tile() == 2) large = v;
+    if (large) return launch_tile<T, TileL, true>(d, a, v, st);
+  }
+  if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);
+  return launch_tile<T, TileS, false>(d, a, v, st);
 }
 
 }  // namespace
@@ -314,6 +374,7 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st) {
   return is_bf16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
 }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_gemm_tile(int v) { g_gemm_tile = v; }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? KCfg<bf16_t>::BK : KCfg<float>::BK; }
 
 }  // namespace vima

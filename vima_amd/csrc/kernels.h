@@ -33,6 +33,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin
+void set_gemm_tile(int v);          // 0 = auto, 1 = force 128x128 tiles, 2 = force 256x256 tiles (bf16)
 
 // ---------------------------------------------------------------- normalisation / elementwise
 // LayerNorm (rms=0: mean/var, affine) or T5 RMSNorm (rms=1: no mean, no bias). fp32 statistics.

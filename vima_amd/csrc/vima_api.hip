@@ -764,6 +764,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   const std::string k = key;
   if (k == "attn_impl") h->attn_impl = (int)value;
   else if (k == "gemm_variant") set_gemm_variant((int)value);
+  else if (k == "gemm_tile") set_gemm_tile((int)value);
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
