@@ -128,13 +128,18 @@ def attn_ref(q, k, v, kmask, relbias, scale, mode):
 
 
 ATTN_CASES = [(0, 2, 12, 64, 64, 64), (0, 1, 12, 100, 100, 64), (1, 3, 8, 8, 40, 32), (1, 2, 24, 71, 300, 32),
-              (2, 2, 8, 9, 9, 32), (2, 3, 24, 71, 71, 32), (1, 2, 4, 5, 33, 64), (2, 1, 4, 40, 40, 64)]
+              (2, 2, 8, 9, 9, 32), (2, 3, 24, 71, 71, 32), (1, 2, 4, 5, 33, 64), (2, 1, 4, 40, 40, 64),
+              (0, 2, 12, 300, 300, 64), (0, 1, 3, 512, 512, 64), (2, 2, 4, 200, 200, 32), (1, 2, 4, 130, 65, 64)]
 
 
-@pytest.mark.parametrize("prec,impl", [("fp32", 0), ("bf16", 0), ("bf16", 1)])
+@pytest.mark.parametrize("prec,impl", [("fp32", 0), ("bf16", 0), ("bf16", 1), ("bf16", 4)])
 @pytest.mark.parametrize("mode,B,H,Lq,Lk,D", ATTN_CASES)
 def test_attention(prec, impl, mode, B, H, Lq, Lk, D):
+    """impl 0 = exact generic kernel, 1 = MFMA flash (1-wave kernel below 64 queries, 4-wave LDS-shared kernel above),
+    4 = MFMA flash with the 4-wave kernel forced for every shape."""
     pol = bare_policy(prec)
+    pol.set_option("attn4_min_lq", 1 if impl == 4 else 64)
+    impl = 1 if impl == 4 else impl
     g = torch.Generator().manual_seed(mode * 100 + Lq + Lk)
     sc = 1.0 if mode else 0.4
     q = torch.randn(B, Lq, H, D, generator=g) * sc

@@ -297,6 +297,207 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
   }
 }
 
+// =============================================================================================== MFMA flash attention, 4 waves
+// Workgroup = 4 waves = 128 queries of one (batch, head); key tiles of 64 are staged ONCE per workgroup in LDS and shared
+// by the 4 waves (K row-major with the GEMM's XOR chunk swizzle -> conflict-free ds_read_b128 A-fragments; V transposed
+// with 136-B rows -> conflict-free ds_read_b64). The next tile's global loads are issued before the current tile is
+// multiplied and written to the other LDS buffer afterwards (register-staged double buffer, one barrier per tile).
+// The T5 relative-position bias (a function of key - query only) and the additive key mask live in LDS for the whole
+// workgroup, so the softmax stage makes no global-memory access. Same S^T = K.Q^T / O^T += V^T.P^T formulation and the
+// same literal mask semantics as attn_mfma_kernel above.
+constexpr int VT4_STRIDE = 68;   // bf16 elements per V^T row: 64 keys + 4 pad = 136 B
+
+template <int D>
+__device__ __forceinline__ int kswz(int r, int c) {
+  if (D == 64) return c ^ ((r >> 1) & 7);   // 128-B rows, 8 chunks
+  return c ^ ((r >> 2) & 3);                // 64-B rows, 4 chunks
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];
+  constexpr int KD = D / 16, OT = D / 32, CPR = D / 8;       // k-steps, O^T tiles, 16-B chunks per K/V row
+  constexpr int ROWB = D * 2;
+  constexpr int KS_BYTES = 64 * ROWB;
+  constexpr int VT_BYTES = D * VT4_STRIDE * 2;
+  constexpr int CH = 64 * CPR / 256;                          // chunks per thread per tile (2 for D=64, 1 for D=32)
+  char* ks_base = smem4;                                       // [2][64][ROWB]
+  bf16_t* vt_base = reinterpret_cast<bf16_t*>(smem4 + 2 * KS_BYTES);   // [2][D][VT4_STRIDE]
+  float* madd = reinterpret_cast<float*>(smem4 + 2 * KS_BYTES + 2 * VT_BYTES);   // [nt*64]
+  const int nt = (p.Lk + 63) / 64;
+  float* btab = madd + nt * 64;                                // [2*Lk-1] (T5 only)
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qi = blockIdx.x * 128 + w * 32 + l31;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q);
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k);
+  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
+
+  // ---- workgroup-wide tables
+  for (int j = tid; j < nt * 64; j += 256) {
+    float v = -INFINITY;                                       // keys beyond Lk never contribute
+    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lk + j]) ? -FLT_MAX : 0.0f;
+    madd[j] = v;
+  }
+  if (MODE == ATTN_T5) {
+    const float* rb = p.relbias + (long long)h * (2 * p.Lk - 1);
+    for (int j = tid; j < 2 * p.Lk - 1; j += 256) btab[j] = rb[j];
+  }
+
+  const int qrow = qi < p.Lq ? qi : p.Lq - 1;
+  bf16x8_t qf[KD];
+#pragma unroll
+  for (int dd = 0; dd < KD; ++dd) {
+    const uint4 u = *reinterpret_cast<const uint4*>(Q + ((long long)b * p.Lq + qrow) * p.ldq + h * D + dd * 16 + hi * 8);
+    qf[dd] = __builtin_bit_cast(bf16x8_t, u);
+  }
+  f32x16_t ot[OT];
+#pragma unroll
+  for (int it = 0; it < OT; ++it)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  uint4 kreg[CH], vreg[CH];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / CPR, c = id % CPR;
+      int row = t * 64 + key;
+      row = row < p.Lk ? row : p.Lk - 1;
+      kreg[i] = *reinterpret_cast<const uint4*>(K + ((long long)b * p.Lk + row) * p.ldk + h * D + c * 8);
+      vreg[i] = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lk + row) * p.ldv + h * D + c * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* ks = ks_base + buf * KS_BYTES;
+    bf16_t* vt = vt_base + buf * (D * VT4_STRIDE);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / CPR, c = id % CPR;
+      *reinterpret_cast<uint4*>(ks + key * ROWB + (kswz<D>(key, c) << 4)) = kreg[i];
+      const uint32_t wds[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(c * 8 + 2 * e) * VT4_STRIDE + key] = (bf16_t)(wds[e] & 0xffffu);
+        vt[(c * 8 + 2 * e + 1) * VT4_STRIDE + key] = (bf16_t)(wds[e] >> 16);
+      }
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(t + 1);                              // in flight while this tile is multiplied
+    const char* ks = ks_base + buf * KS_BYTES;
+    const bf16_t* vt = vt_base + buf * (D * VT4_STRIDE);
+    const int k0 = t * 64;
+    // ---- S^T for the two 32-key sub-tiles
+    f32x16_t s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+      const int row = sub * 32 + l31;
+#pragma unroll
+      for (int dd = 0; dd < KD; ++dd) {
+        const uint4 u = *reinterpret_cast<const uint4*>(ks + row * ROWB + (kswz<D>(row, dd * 2 + hi) << 4));
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s[sub], 0, 0, 0);
+      }
+    }
+    // ---- scores -> probabilities
+    float x[2][16];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key = k0 + sub * 32 + 8 * g + 4 * hi;        // 4 consecutive keys key..key+3 (multiple of 4)
+        const float4 ma = *reinterpret_cast<const float4*>(madd + key);
+        const float mav[4] = {ma.x, ma.y, ma.z, ma.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sv = s[sub][4 * g + e];
+          float v;
+          if (MODE == ATTN_T5) {
+            int bi = (key + e) - qi + p.Lk - 1;
+            bi = bi < 0 ? 0 : (bi > 2 * p.Lk - 2 ? 2 * p.Lk - 2 : bi);
+            v = sv + (btab[bi] + mav[e]);
+          } else if (MODE == ATTN_CROSS) {
+            v = sv * p.scale + mav[e];
+          } else {
+            v = sv * p.scale;
+            if (key + e > qi) v = -1e4f;
+            v = v + mav[e];
+          }
+          x[sub][4 * g + e] = v;
+          mt = fmaxf(mt, v);
+        }
+      }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __expf(m_run - m_new);
+    uint32_t pk[2][8];
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __expf(x[sub][r] - m_new), p1 = __expf(x[sub][r + 1] - m_new);
+        const uint32_t u = pack2_bf16(p0, p1);
+        pk[sub][r >> 1] = u;
+        rs += __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u);
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint4 pu;
+        pu.x = pk[sub][half * 4 + 0]; pu.y = pk[sub][half * 4 + 1]; pu.z = pk[sub][half * 4 + 2]; pu.w = pk[sub][half * 4 + 3];
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+        for (int it = 0; it < OT; ++it) {
+          const bf16_t* vr = vt + (it * 32 + l31) * VT4_STRIDE + sub * 32 + 16 * half + 4 * hi;
+          const uint2 a0 = *reinterpret_cast<const uint2*>(vr);
+          const uint2 a1 = *reinterpret_cast<const uint2*>(vr + 8);
+          uint4 vu;
+          vu.x = a0.x; vu.y = a0.y; vu.z = a1.x; vu.w = a1.y;
+          ot[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vu), pf, ot[it], 0, 0, 0);
+        }
+      }
+    if (t + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (qi < p.Lq) {
+    const float inv = 1.0f / l_run;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + ((long long)b * p.Lq + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = it * 32 + 8 * g + 4 * hi;
+        store4(op + d, make_float4(ot[it][4 * g] * inv, ot[it][4 * g + 1] * inv, ot[it][4 * g + 2] * inv,
+                                   ot[it][4 * g + 3] * inv));
+      }
+  }
+}
+
 inline AttnDev to_dev(const AttnArgs& a) {
   AttnDev d;
   d.q = a.q; d.ldq = a.ldq; d.k = a.k; d.ldk = a.ldk; d.v = a.v; d.ldv = a.ldv; d.out = a.out; d.ldo = a.ldo;
@@ -334,6 +535,27 @@ int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+int g_attn4_min_lq = 64;   // queries per (batch, head) from which the 4-wave LDS-shared kernel is used
+void set_attn4_min_lq(int v) { g_attn4_min_lq = v; }
+
+template <int D, int MODE>
+static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
+  const int nt = (a.Lk + 63) / 64;
+  const size_t sh = 2 * (64 * D * 2) + 2 * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 +
+                    (MODE == ATTN_T5 ? (size_t)(2 * a.Lk) * 4 : 0);
+  if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma4_kernel<D, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid((unsigned)((a.Lq + 127) / 128), (unsigned)a.H, (unsigned)a.B);
+  hipLaunchKernelGGL((attn_mfma4_kernel<D, MODE>), grid, dim3(256), sh, st, d);
+  return (int)hipGetLastError();
+}
+
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
   if (a.D != 32 && a.D != 64) return (int)hipErrorInvalidValue;
@@ -341,6 +563,16 @@ int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
   // 16-byte fragment loads: rows and head offsets must be 16-B aligned
   if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) return (int)hipErrorInvalidValue;
   const AttnDev d = to_dev(a);
+  if (a.Lq >= g_attn4_min_lq) {
+    if (a.D == 32) {
+      if (a.mode == ATTN_T5) return launch_mfma4<32, ATTN_T5>(d, a, st);
+      if (a.mode == ATTN_CROSS) return launch_mfma4<32, ATTN_CROSS>(d, a, st);
+      return launch_mfma4<32, ATTN_CAUSAL>(d, a, st);
+    }
+    if (a.mode == ATTN_T5) return launch_mfma4<64, ATTN_T5>(d, a, st);
+    if (a.mode == ATTN_CROSS) return launch_mfma4<64, ATTN_CROSS>(d, a, st);
+    return launch_mfma4<64, ATTN_CAUSAL>(d, a, st);
+  }
   dim3 grid((unsigned)((a.Lq + 31) / 32), (unsigned)a.H, (unsigned)a.B);
 #define VIMA_ATTN(D_, M_) hipLaunchKernelGGL((attn_mfma_kernel<D_, M_>), grid, dim3(64), 0, st, d)
   if (a.D == 32) {

@@ -765,6 +765,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   if (k == "attn_impl") h->attn_impl = (int)value;
   else if (k == "gemm_variant") set_gemm_variant((int)value);
   else if (k == "gemm_tile") set_gemm_tile((int)value);
+  else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
