@@ -44,6 +44,20 @@ def flops_per_sample(E, N, Lp, n_prompt_obj, Q, T):
     return prompt + step, step
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant (GEMM) kernel from the committed rocprofv3 PMC passes (profiles/): the
+    counters need their own profiler runs (FETCH_SIZE and WRITE_SIZE do not fit one pass), so bench.py reports the
+    last committed measurement of this same command rather than collecting it live. None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return round(float(json.load(open(files[-1]))["gemm_bf16_bytes_per_launch"]), 1)
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """Cores this process may actually use (affinity mask and cgroup CPU quota), not the host's os.cpu_count()."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -187,7 +201,7 @@ def main():
     roofline = {
         "bound": "mfma", "kernel": "vima::gemm_kernel (bf16 mfma_f32_32x32x16)" if args.precision == "bf16" else "vima::gemm_kernel (fp32 mfma)",
         "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
-        "traffic": None,
+        "traffic": pmc_traffic(),
         "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / max(gemm["launches"], 1), 2),
         "gemm_ms_per_step": round(gemm["ms"], 3), "attention_ms_per_step": round(prof["attention"]["ms"], 3),
         "other_ms_per_step": round(prof["other"]["ms"], 3),

@@ -1,0 +1,51 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (rocpd SQLite) per kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads
+(guides/MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is used as reported.
+usage: python scripts/pmc_summary.py <fetch.db> <write.db> <out.md> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    out = {}
+    for name, n, avg, tot in c.execute(
+            "select kernel_name, count(*), avg(value), sum(value) from counters_collection where counter_name=? group by kernel_name",
+            (counter,)):
+        out[name] = (n, avg, tot)
+    return out
+
+
+def short(name):
+    s = name.replace("vima::(anonymous namespace)::", "vima::").replace("void ", "")
+    return s.split("(")[0][:100]
+
+
+def main():
+    fdb, wdb, out_md, out_json = sys.argv[1:5]
+    f = per_kernel(fdb, "FETCH_SIZE")
+    w = per_kernel(wdb, "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, (0, 0, 0))[2] + w.get(k, (0, 0, 0))[2])):
+        nf, af, tf = f.get(k, (0, 0.0, 0.0))
+        nw, aw, tw = w.get(k, (0, 0.0, 0.0))
+        rows.append((short(k), nf, af, aw, (2 * af + aw) * 1024))
+    gem = [r for r in rows if "gemm_kernel<unsigned short" in r[0]]
+    n = sum(r[1] for r in gem)
+    gem_bytes = sum(r[1] * r[4] for r in gem) / max(n, 1)
+    with open(out_md, "w") as fh:
+        fh.write("# HBM traffic per kernel launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs)\n\n")
+        fh.write("bytes/launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE half-count correction per MI355X_MICROARCH.md)\n\n")
+        fh.write("| kernel | launches | avg FETCH_SIZE KiB | avg WRITE_SIZE KiB | corrected MB / launch |\n|---|---|---|---|---|\n")
+        for r in rows[:25]:
+            fh.write(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.0f} | {r[4] / 1e6:.1f} |\n")
+        fh.write(f"\nAll bf16 `gemm_kernel` instantiations: {n} launches, {gem_bytes / 1e6:.1f} MB per launch on average.\n")
+    json.dump({"gemm_bf16_launches": n, "gemm_bf16_bytes_per_launch": gem_bytes,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0",
+               "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950 half-count)"}, open(out_json, "w"), indent=1)
+    print("gemm bf16:", n, "launches,", gem_bytes / 1e6, "MB/launch")
+
+
+if __name__ == "__main__":
+    main()

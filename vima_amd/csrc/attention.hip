@@ -80,6 +80,70 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
   for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
 }
 
+// Last ViT block: only the cls token (token 0) is read by ln_post (vit.py:186), so only its query is needed.
+// q: T [M, W] (cls rows), kv: T [M*S, 2W] (K | V of every token) -> out T [M, W]. One thread per (crop, head).
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__ qb, const T* __restrict__ kv,
+                                                            T* __restrict__ out, long long total, int S, int W, int heads) {
+  constexpr int D = 32;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int h = (int)(idx % heads);
+  const long long m = idx / heads;
+  const int ld = 2 * W;
+  const T* qp = qb + m * W + h * D;
+  float q[D];
+#pragma unroll
+  for (int c = 0; c < D; c += 4) {
+    const float4 v = load4(qp + c);
+    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
+  }
+  const float scale = 0.17677669529663687f;
+  float s[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = -INFINITY;
+    if (j < S) {
+      const T* kp = kv + (m * S + j) * ld + h * D;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; c += 4) {
+        const float4 v = load4(kp + c);
+        d = fmaf(q[c], v.x, d); d = fmaf(q[c + 1], v.y, d); d = fmaf(q[c + 2], v.z, d); d = fmaf(q[c + 3], v.w, d);
+      }
+      s[j] = d * scale;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = j < S ? expf(s[j] - mx) : 0.f;
+    l += s[j];
+  }
+  const float inv = 1.0f / l;
+  float o[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < S) {
+      const T* vp = kv + (m * S + j) * ld + W + h * D;
+      const float pj = s[j] * inv;
+#pragma unroll
+      for (int c = 0; c < D; c += 4) {
+        const float4 v = load4(vp + c);
+        o[c] = fmaf(pj, v.x, o[c]); o[c + 1] = fmaf(pj, v.y, o[c + 1]);
+        o[c + 2] = fmaf(pj, v.z, o[c + 2]); o[c + 3] = fmaf(pj, v.w, o[c + 3]);
+      }
+    }
+  }
+  T* op = out + m * W + h * D;
+#pragma unroll
+  for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
+}
+
 // =============================================================================================== generic exact kernel
 struct AttnDev {
   const void* q; int ldq;
@@ -329,8 +393,15 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int qi = blockIdx.x * 128 + w * 32 + l31;
+  // XCD-aware order (workgroup id % 8 = XCD): the query blocks of one (batch, head) run back to back on ONE XCD so its
+  // K/V (re-read by every query block) stay in that XCD's L2: id = ((bh / 8) * nq + qblk) * 8 + bh % 8
+  const int nq = (p.Lq + 127) / 128;
+  const int bid = blockIdx.x;
+  const int bh = (bid / (8 * nq)) * 8 + (bid & 7);
+  const int qblk = (bid >> 3) % nq;
+  if (bh >= p.B * p.H) return;
+  const int h = bh % p.H, b = bh / p.H;
+  const int qi = qblk * 128 + w * 32 + l31;
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q);
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k);
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
@@ -518,6 +589,16 @@ int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, 
   return (int)hipGetLastError();
 }
 
+int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (S > 8 || W / heads != 32 || W % heads) return (int)hipErrorInvalidValue;
+  const long long total = (long long)M * heads;
+  const unsigned g = (unsigned)((total + 255) / 256);
+  if (is_bf16) hipLaunchKernelGGL(vit_attn_cls_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, total, S, W, heads);
+  else hipLaunchKernelGGL(vit_attn_cls_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)out, total, S, W, heads);
+  return (int)hipGetLastError();
+}
+
 int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
   if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
   if (a.D != 32 && a.D != 64) return (int)hipErrorInvalidValue;
@@ -551,7 +632,9 @@ static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  dim3 grid((unsigned)((a.Lq + 127) / 128), (unsigned)a.H, (unsigned)a.B);
+  const int nq = (a.Lq + 127) / 128;
+  const int bh8 = (a.B * a.H + 7) / 8;
+  dim3 grid((unsigned)(bh8 * 8 * nq), 1, 1);
   hipLaunchKernelGGL((attn_mfma4_kernel<D, MODE>), grid, dim3(256), sh, st, d);
   return (int)hipGetLastError();
 }

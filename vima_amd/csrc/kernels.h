@@ -73,6 +73,8 @@ int launch_gather_pred(const float* x, float* out, int T, int B, int Q, int Lq, 
 // ---------------------------------------------------------------- attention
 // ViT: 5-token (S <= 8) multi-head attention on packed qkv T [M*S, 3*W] -> T [M*S, W]; head dim 32
 int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st);
+// last ViT block: cls-token query only. q T [M, W], kv T [M*S, 2W] -> out T [M, W]
+int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st);
 
 enum AttnMode : int { ATTN_T5 = 0, ATTN_CROSS = 1, ATTN_CAUSAL = 2 };
 struct AttnArgs {

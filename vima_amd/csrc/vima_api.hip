@@ -125,6 +125,7 @@ struct VimaHandle {
   bool finalized = false;
   int attn_impl = 1;
   int vit_chunk = 16384;
+  int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
   std::map<std::string, HostParam> host;       // staged until finalize
   std::vector<void*> owned;                     // device allocations of packed weights
   Arena arena;
@@ -553,7 +554,8 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
     R.linear(P, kVitW, h->vit.conv, mc * 4, ACT_NONE, nullptr, 0, nullptr, 0, pre, kVitW, nullptr, 0);
     OTHER(R, launch_vit_embed(pre, h->vit.cls, h->vit.pos, h->vit.lnpre_g, h->vit.lnpre_b, x, mc, R.st), "vit_embed");
     const int rows = mc * 5;
-    for (int j = 0; j < kVitLayers; ++j) {
+    const bool prune = h->vit_prune_last != 0;
+    for (int j = 0; j < kVitLayers - (prune ? 1 : 0); ++j) {
       auto& B = h->vit.blk[j];
       R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, hT);
       R.linear(hT, kVitW, B.in_proj, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * kVitW);
@@ -566,8 +568,34 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
       R.linear(hT, kVitW, B.fc, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, u, 4 * kVitW);
       R.linear(u, 4 * kVitW, B.proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
     }
+    const float* xpost = x;        // rows ln_post reads (cls token of every crop)
+    long long ld_post = 5 * kVitW;
+    if (prune) {
+      // Last block: ln_post only reads the cls row (vit.py:186), so everything after the K/V projection is computed
+      // for the cls token only (identical values for that row; the other 4 rows of the block output are never read).
+      auto& B = h->vit.blk[kVitLayers - 1];
+      R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, hT);
+      GemmArgs kvg;   // K,V of all 5 tokens: in_proj rows [W, 3W)
+      kvg.A = hT; kvg.lda = kVitW; kvg.W = R.offT(B.in_proj.W, (long long)kVitW * kVitW); kvg.ldw = kVitW;
+      kvg.M = rows; kvg.N = 2 * kVitW; kvg.K = kVitW; kvg.bias = B.in_proj.b + kVitW; kvg.outT = qkv; kvg.ldT = 2 * kVitW;
+      R.gemm(kvg);
+      GemmArgs qg;    // Q of the cls token only: in_proj rows [0, W), A rows strided by 5 tokens
+      qg.A = hT; qg.lda = 5 * kVitW; qg.W = B.in_proj.W; qg.ldw = kVitW; qg.M = mc; qg.N = kVitW; qg.K = kVitW;
+      qg.bias = B.in_proj.b; qg.outT = y; qg.ldT = kVitW;
+      R.gemm(qg);
+      R.prof_begin(1, 4.0 * mc * kVitHeads * 5.0 * 32);
+      int e = launch_vit_attn_cls(y, qkv, att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
+      R.prof_end();
+      R.other(e, "vit_attn_cls");
+      R.linear(att, kVitW, B.out_proj, mc, ACT_NONE, nullptr, 0, x, 5 * kVitW, pre, kVitW, nullptr, 0);   // xc = x_cls + attn
+      R.ln(pre, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, mc, kVitW, nullptr, hT);
+      R.linear(hT, kVitW, B.fc, mc, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, u, 4 * kVitW);
+      R.linear(u, 4 * kVitW, B.proj, mc, ACT_NONE, nullptr, 0, pre, kVitW, pre, kVitW, nullptr, 0);
+      xpost = pre;
+      ld_post = kVitW;
+    }
     // ln_post on the cls rows, then @ projection into cat[:, 0:768]   (vit.py:186-189)
-    R.ln(x, 5 * kVitW, h->vit.lnpost_g, h->vit.lnpost_b, 1e-5f, 0, mc, kVitW, nullptr, y);
+    R.ln(xpost, ld_post, h->vit.lnpost_g, h->vit.lnpost_b, 1e-5f, 0, mc, kVitW, nullptr, y);
     R.linear(y, kVitW, h->vit.projection, mc, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0,
              R.offT(cat, (long long)r0 * 2 * kVitW), 2 * kVitW);
     if (R.err) return R.err;
@@ -767,6 +795,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_tile") set_gemm_tile((int)value);
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
+  else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
 }
