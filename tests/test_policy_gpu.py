@@ -100,6 +100,22 @@ def test_invariances_fp32():
     assert max_abs(shorter, base[:2]) < 1e-5
 
 
+def test_dual_stream_and_pruning_are_exact():
+    """The two-stream software pipelining (batch halves / ViT chunks / prompt K/V on an auxiliary stream) and the
+    cls-only last ViT block only reorder or skip never-read work: results must be bit-identical to the plain path."""
+    cfg, wseed, prompts, obs, actions = build_case("e384_long")
+    sd = syn.make_state_dict(cfg, wseed)
+    outs = []
+    for dual, prune, chunk in [(0, 0, 16384), (1, 1, 16384), (1, 0, 7), (0, 1, 5)]:
+        pol = loaded_policy(cfg, sd, "bf16", dual_stream=dual, vit_prune_last=prune, vit_chunk=chunk)
+        for _ in range(2):   # second pass exercises the steady-state (consolidated) workspace
+            o = native_outputs(pol, prompts, obs, actions)
+        outs.append(o)
+    for o in outs[1:]:
+        for k in ("prompt_tokens", "obs_tokens", "predicted", "raw_logits"):
+            assert torch.equal(o[k], outs[0][k]), k
+
+
 def test_errors_mirror_reference():
     cfg = syn.config("2M")
     sd = syn.make_state_dict(cfg, 0)

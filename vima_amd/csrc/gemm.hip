@@ -117,6 +117,10 @@ struct GemmDev {
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
   int mtiles, ntiles;
+  int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
+  int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
+  int spread;   // LDS-DMA issue: 0 = whole next slice at the top of the current one, 1 = spread over the k-steps
+  int prio;     // s_setprio(1) around the MFMA clusters
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
@@ -136,10 +140,27 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
 
   // XCD-aware tile mapping (block b runs on XCD b % 8): one XCD walks all n-tiles of its A panel back to back
   const int bid = blockIdx.x;
-  const int xcd = bid & 7;
-  const int idx = bid >> 3;
-  const int tn = idx % p.ntiles;
-  const int tm = (idx / p.ntiles) * 8 + xcd;
+  int tm, tn;
+  if (p.raster == 2) {
+    tn = bid % p.ntiles;
+    tm = bid / p.ntiles;
+  } else {
+    const int xcd = bid & 7;
+    const int idx = bid >> 3;
+    if (p.raster == 0) {
+      tn = idx % p.ntiles;
+      tm = (idx / p.ntiles) * 8 + xcd;
+    } else {
+      const int mtx = (p.mtiles + 7) >> 3;                 // A panels per XCD
+      const int full = p.ntiles / p.ngroup;                // complete n-groups
+      const int per_group = mtx * p.ngroup;
+      int g = idx / per_group, rem, ng;
+      if (g < full) { rem = idx - g * per_group; ng = p.ngroup; }
+      else { g = full; rem = idx - full * per_group; ng = p.ntiles - full * p.ngroup; }
+      tn = g * p.ngroup + rem % ng;
+      tm = (rem / ng) * 8 + xcd;
+    }
+  }
   if (tm >= p.mtiles) return;
   const int z = blockIdx.y;
   const int m0 = tm * TL::BM, n0 = tn * TL::BN;
@@ -213,19 +234,26 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fw[nb][ni].load(sW, wrow + ni * 32, kk + 1, hi);
       }
-      // this step's share of the next K-slice's LDS-DMA (spread over the steps: the first MFMAs after the barrier
-      // wait only for LDS latency, not for a burst of 8 VMEM issues)
+      // the next K-slice's LDS-DMA: p.spread == 0: all pieces right after the first fragment reads, so every piece has
+      // the whole slice of MFMAs to land before the vmcnt(0) at the slice end; p.spread == 1: spread over the k-steps
       if (more) {
+        if (p.spread) {
 #pragma unroll
-        for (int j = kk * NP / KSTEPS; j < (kk + 1) * NP / KSTEPS; ++j) issue_piece(cur ^ 1, kt + 1, j);
+          for (int j = kk * NP / KSTEPS; j < (kk + 1) * NP / KSTEPS; ++j) issue_piece(cur ^ 1, kt + 1, j);
+        } else if (kk == 0) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) issue_piece(cur ^ 1, kt + 1, j);
+        }
       }
       // pin the order: [ds_reads of step kk+1, DMA issue] then [MFMAs of step kk]; without this hipcc re-serialises
       // read -> wait -> 2 MFMAs on one register set and the LDS latency is exposed
       __builtin_amdgcn_sched_barrier(0);
+      if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+      if (p.prio) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     wait_all_and_barrier();
@@ -288,6 +316,7 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
 // 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin (TileS only). Override with VIMA_GEMM_VARIANT.
 int g_gemm_variant = -1;
 int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL (bf16 only)
+int g_gemm_raster = -1; // see GemmDev::raster
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && e[0]) ? atoi(e) : dflt;
@@ -295,6 +324,15 @@ inline int env_int(const char* name, int dflt) {
 inline int gemm_variant() {
   if (g_gemm_variant < 0) g_gemm_variant = env_int("VIMA_GEMM_VARIANT", 1) ? 1 : 0;
   return g_gemm_variant;
+}
+int g_gemm_spread = -1, g_gemm_prio = -1;
+inline int env_cached(const char* name, int& cache, int dflt) {
+  if (cache < 0) cache = env_int(name, dflt);
+  return cache;
+}
+inline int gemm_raster() {
+  if (g_gemm_raster < 0) g_gemm_raster = env_int("VIMA_GEMM_RASTER", 0);
+  return g_gemm_raster;
 }
 inline int gemm_tile() {
   if (g_gemm_tile < 0) g_gemm_tile = env_int("VIMA_GEMM_TILE", 0);
@@ -321,7 +359,17 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.mtiles = (a.M + TL::BM - 1) / TL::BM;
   d.ntiles = (a.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  d.raster = gemm_raster();
+  d.spread = env_cached("VIMA_GEMM_SPREAD", g_gemm_spread, 0);
+  d.prio = env_cached("VIMA_GEMM_PRIO", g_gemm_prio, 0);
+  {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
+    const long long panel = (long long)TL::BN * a.K * (long long)sizeof(T);
+    long long ng = (3LL << 19) / (panel > 0 ? panel : 1);
+    if (ng < 1) ng = 1;
+    if (ng > d.ntiles) ng = d.ntiles;
+    d.ngroup = (int)ng;
+  }
+  dim3 grid((unsigned)(d.raster == 2 ? d.mtiles * d.ntiles : groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
   if (!vec) return launch_inst<T, TL, -1, false, ASMLDS>(d, grid, st);
   switch (a.act) {
     case ACT_NONE: return launch_inst<T, TL, ACT_NONE, true, ASMLDS>(d, grid, st);
@@ -375,6 +423,9 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st) {
 }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_tile(int v) { g_gemm_tile = v; }
+void set_gemm_raster(int v) { g_gemm_raster = v; }
+void set_gemm_spread(int v) { g_gemm_spread = v; }
+void set_gemm_prio(int v) { g_gemm_prio = v; }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? KCfg<bf16_t>::BK : KCfg<float>::BK; }
 
 }  // namespace vima

@@ -126,6 +126,11 @@ struct VimaHandle {
   int attn_impl = 1;
   int vit_chunk = 16384;
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
+  int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
+                            // GEMM epilogues) of one half overlap the MFMA-bound GEMM main loops of the other half
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::vector<hipEvent_t> ev_layer;   // per decoder layer: "prompt K/V of layer i projected" (aux -> main)
   std::map<std::string, HostParam> host;       // staged until finalize
   std::vector<void*> owned;                     // device allocations of packed weights
   Arena arena;
@@ -520,6 +525,82 @@ struct Run {
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ stages
+// aux stream starts after everything already queued on the caller's stream / caller's stream waits for aux
+int fork_aux(Run& R) {
+  HIPCK(hipEventRecord(R.h->ev_fork, R.st));
+  HIPCK(hipStreamWaitEvent(R.h->aux, R.h->ev_fork, 0));
+  return 0;
+}
+int join_aux(Run& R) {
+  HIPCK(hipEventRecord(R.h->ev_join, R.h->aux));
+  HIPCK(hipStreamWaitEvent(R.st, R.h->ev_join, 0));
+  return 0;
+}
+
+struct VitBuf { void* P; float* pre; float* x; void *hT, *qkv, *att, *u, *y; };
+
+// ViT (vit.py:171-191) on internal crop rows [r0, r0+mc) -> cat[r0.., 0:768]
+void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int mc, const VitBuf& b, void* cat) {
+  VimaHandle* h = R.h;
+  // patchify, honouring the view boundary inside the chunk
+  for (int vi = 0; vi < 2; ++vi) {
+    const int lo = r0 > vi * per_view ? r0 : vi * per_view;
+    const int hi_ = (r0 + mc) < (vi + 1) * per_view ? (r0 + mc) : (vi + 1) * per_view;
+    if (hi_ > lo)
+      OTHER(R, launch_patchify(crops[vi] + (size_t)(lo - vi * per_view) * 3072, R.offT(b.P, (long long)(lo - r0) * 4 * kVitW),
+                               hi_ - lo, h->bf16, R.st), "patchify");
+  }
+  // conv1 as GEMM (vit.py:172), fp32 out
+  R.linear(b.P, kVitW, h->vit.conv, mc * 4, ACT_NONE, nullptr, 0, nullptr, 0, b.pre, kVitW, nullptr, 0);
+  OTHER(R, launch_vit_embed(b.pre, h->vit.cls, h->vit.pos, h->vit.lnpre_g, h->vit.lnpre_b, b.x, mc, R.st), "vit_embed");
+  const int rows = mc * 5;
+  const bool prune = h->vit_prune_last != 0;
+  float* x = b.x;
+  for (int j = 0; j < kVitLayers - (prune ? 1 : 0); ++j) {
+    auto& B = h->vit.blk[j];
+    R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
+    R.linear(b.hT, kVitW, B.in_proj, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, b.qkv, 3 * kVitW);
+    R.prof_begin(1, 4.0 * mc * kVitHeads * 25.0 * 32);
+    int e = launch_vit_attn(b.qkv, b.att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
+    R.prof_end();
+    R.other(e, "vit_attn");
+    R.linear(b.att, kVitW, B.out_proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
+    R.ln(x, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
+    R.linear(b.hT, kVitW, B.fc, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, 4 * kVitW);
+    R.linear(b.u, 4 * kVitW, B.proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
+  }
+  const float* xpost = x;        // rows ln_post reads (cls token of every crop)
+  long long ld_post = 5 * kVitW;
+  if (prune) {
+    // Last block: ln_post only reads the cls row (vit.py:186), so everything after the K/V projection is computed
+    // for the cls token only (identical values for that row; the other 4 rows of the block output are never read).
+    auto& B = h->vit.blk[kVitLayers - 1];
+    R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
+    GemmArgs kvg;   // K,V of all 5 tokens: in_proj rows [W, 3W)
+    kvg.A = b.hT; kvg.lda = kVitW; kvg.W = R.offT(B.in_proj.W, (long long)kVitW * kVitW); kvg.ldw = kVitW;
+    kvg.M = rows; kvg.N = 2 * kVitW; kvg.K = kVitW; kvg.bias = B.in_proj.b + kVitW; kvg.outT = b.qkv; kvg.ldT = 2 * kVitW;
+    R.gemm(kvg);
+    GemmArgs qg;    // Q of the cls token only: in_proj rows [0, W), A rows strided by 5 tokens
+    qg.A = b.hT; qg.lda = 5 * kVitW; qg.W = B.in_proj.W; qg.ldw = kVitW; qg.M = mc; qg.N = kVitW; qg.K = kVitW;
+    qg.bias = B.in_proj.b; qg.outT = b.y; qg.ldT = kVitW;
+    R.gemm(qg);
+    R.prof_begin(1, 4.0 * mc * kVitHeads * 5.0 * 32);
+    int e = launch_vit_attn_cls(b.y, b.qkv, b.att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
+    R.prof_end();
+    R.other(e, "vit_attn_cls");
+    R.linear(b.att, kVitW, B.out_proj, mc, ACT_NONE, nullptr, 0, x, 5 * kVitW, b.pre, kVitW, nullptr, 0);   // xc = x_cls + attn
+    R.ln(b.pre, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, mc, kVitW, nullptr, b.hT);
+    R.linear(b.hT, kVitW, B.fc, mc, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, 4 * kVitW);
+    R.linear(b.u, 4 * kVitW, B.proj, mc, ACT_NONE, nullptr, 0, b.pre, kVitW, b.pre, kVitW, nullptr, 0);
+    xpost = b.pre;
+    ld_post = kVitW;
+  }
+  // ln_post on the cls rows, then @ projection into cat[:, 0:768]   (vit.py:186-189)
+  R.ln(xpost, ld_post, h->vit.lnpost_g, h->vit.lnpost_b, 1e-5f, 0, mc, kVitW, nullptr, b.y);
+  R.linear(b.y, kVitW, h->vit.projection, mc, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0,
+           R.offT(cat, (long long)r0 * 2 * kVitW), 2 * kVitW);
+}
+
 // ObjEncoder.forward (obj_encoder.py:66-95). Produces featT [n*2qv, E] (T) and optionally feat32 (fp32).
 int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[2], int n, int qv, float* feat32,
                void* featT) {
@@ -529,77 +610,35 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
   const int M = 2 * per_view;   // internal crop row r = view * per_view + (i*qv + q)
   if (M == 0) return 0;
   void* cat = R.wsT((size_t)M * 2 * kVitW);   // [M, 1536] = [vit feature | bbox feature]
-  const int chunk = h->vit_chunk > 0 ? h->vit_chunk : M;
-  const int mc_max = M < chunk ? M : chunk;
-  void* P = R.wsT((size_t)mc_max * 4 * kVitW);
-  float* pre = R.ws<float>((size_t)mc_max * 4 * kVitW);
-  float* x = R.ws<float>((size_t)mc_max * 5 * kVitW);
-  void* hT = R.wsT((size_t)mc_max * 5 * kVitW);
-  void* qkv = R.wsT((size_t)mc_max * 5 * 3 * kVitW);
-  void* att = R.wsT((size_t)mc_max * 5 * kVitW);
-  void* u = R.wsT((size_t)mc_max * 5 * 4 * kVitW);
-  void* y = R.wsT((size_t)mc_max * kVitW);
-  if (R.err) return R.err;
-  for (int r0 = 0; r0 < M; r0 += chunk) {
-    const int mc = (M - r0) < chunk ? (M - r0) : chunk;
-    // patchify, honouring the view boundary inside the chunk
-    for (int vi = 0; vi < 2; ++vi) {
-      const int lo = r0 > vi * per_view ? r0 : vi * per_view;
-      const int hi_ = (r0 + mc) < (vi + 1) * per_view ? (r0 + mc) : (vi + 1) * per_view;
-      if (hi_ > lo)
-        OTHER(R, launch_patchify(crops[vi] + (size_t)(lo - vi * per_view) * 3072, R.offT(P, (long long)(lo - r0) * 4 * kVitW),
-                                 hi_ - lo, h->bf16, R.st), "patchify");
-    }
-    // conv1 as GEMM (vit.py:172), fp32 out
-    R.linear(P, kVitW, h->vit.conv, mc * 4, ACT_NONE, nullptr, 0, nullptr, 0, pre, kVitW, nullptr, 0);
-    OTHER(R, launch_vit_embed(pre, h->vit.cls, h->vit.pos, h->vit.lnpre_g, h->vit.lnpre_b, x, mc, R.st), "vit_embed");
-    const int rows = mc * 5;
-    const bool prune = h->vit_prune_last != 0;
-    for (int j = 0; j < kVitLayers - (prune ? 1 : 0); ++j) {
-      auto& B = h->vit.blk[j];
-      R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, hT);
-      R.linear(hT, kVitW, B.in_proj, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * kVitW);
-      R.prof_begin(1, 4.0 * mc * kVitHeads * 25.0 * 32);
-      int e = launch_vit_attn(qkv, att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
-      R.prof_end();
-      R.other(e, "vit_attn");
-      R.linear(att, kVitW, B.out_proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
-      R.ln(x, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, rows, kVitW, nullptr, hT);
-      R.linear(hT, kVitW, B.fc, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, u, 4 * kVitW);
-      R.linear(u, 4 * kVitW, B.proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
-    }
-    const float* xpost = x;        // rows ln_post reads (cls token of every crop)
-    long long ld_post = 5 * kVitW;
-    if (prune) {
-      // Last block: ln_post only reads the cls row (vit.py:186), so everything after the K/V projection is computed
-      // for the cls token only (identical values for that row; the other 4 rows of the block output are never read).
-      auto& B = h->vit.blk[kVitLayers - 1];
-      R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, hT);
-      GemmArgs kvg;   // K,V of all 5 tokens: in_proj rows [W, 3W)
-      kvg.A = hT; kvg.lda = kVitW; kvg.W = R.offT(B.in_proj.W, (long long)kVitW * kVitW); kvg.ldw = kVitW;
-      kvg.M = rows; kvg.N = 2 * kVitW; kvg.K = kVitW; kvg.bias = B.in_proj.b + kVitW; kvg.outT = qkv; kvg.ldT = 2 * kVitW;
-      R.gemm(kvg);
-      GemmArgs qg;    // Q of the cls token only: in_proj rows [0, W), A rows strided by 5 tokens
-      qg.A = hT; qg.lda = 5 * kVitW; qg.W = B.in_proj.W; qg.ldw = kVitW; qg.M = mc; qg.N = kVitW; qg.K = kVitW;
-      qg.bias = B.in_proj.b; qg.outT = y; qg.ldT = kVitW;
-      R.gemm(qg);
-      R.prof_begin(1, 4.0 * mc * kVitHeads * 5.0 * 32);
-      int e = launch_vit_attn_cls(y, qkv, att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
-      R.prof_end();
-      R.other(e, "vit_attn_cls");
-      R.linear(att, kVitW, B.out_proj, mc, ACT_NONE, nullptr, 0, x, 5 * kVitW, pre, kVitW, nullptr, 0);   // xc = x_cls + attn
-      R.ln(pre, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, mc, kVitW, nullptr, hT);
-      R.linear(hT, kVitW, B.fc, mc, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, u, 4 * kVitW);
-      R.linear(u, 4 * kVitW, B.proj, mc, ACT_NONE, nullptr, 0, pre, kVitW, pre, kVitW, nullptr, 0);
-      xpost = pre;
-      ld_post = kVitW;
-    }
-    // ln_post on the cls rows, then @ projection into cat[:, 0:768]   (vit.py:186-189)
-    R.ln(xpost, ld_post, h->vit.lnpost_g, h->vit.lnpost_b, 1e-5f, 0, mc, kVitW, nullptr, y);
-    R.linear(y, kVitW, h->vit.projection, mc, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0,
-             R.offT(cat, (long long)r0 * 2 * kVitW), 2 * kVitW);
-    if (R.err) return R.err;
+  // equal-size chunks (crops are independent); with dual_stream an even number of them, alternating between streams
+  const int cmax = h->vit_chunk > 0 ? h->vit_chunk : M;
+  const bool dual = h->dual_stream && M >= 512;
+  int nchunks = (M + cmax - 1) / cmax;
+  if (dual && (nchunks & 1)) ++nchunks;
+  if (dual && nchunks < 2) nchunks = 2;
+  const int chunk = (M + nchunks - 1) / nchunks;
+  VitBuf vb[2];
+  for (int i = 0; i < (dual ? 2 : 1); ++i) {
+    vb[i].P = R.wsT((size_t)chunk * 4 * kVitW);
+    vb[i].pre = R.ws<float>((size_t)chunk * 4 * kVitW);
+    vb[i].x = R.ws<float>((size_t)chunk * 5 * kVitW);
+    vb[i].hT = R.wsT((size_t)chunk * 5 * kVitW);
+    vb[i].qkv = R.wsT((size_t)chunk * 5 * 3 * kVitW);
+    vb[i].att = R.wsT((size_t)chunk * 5 * kVitW);
+    vb[i].u = R.wsT((size_t)chunk * 5 * 4 * kVitW);
+    vb[i].y = R.wsT((size_t)chunk * kVitW);
   }
+  if (R.err) return R.err;
+  Run Rb{h, h->aux};
+  if (dual && fork_aux(R)) return R.err = 1;
+  int ci = 0;
+  for (int r0 = 0; r0 < M; r0 += chunk, ++ci) {
+    const int mc = (M - r0) < chunk ? (M - r0) : chunk;
+    Run& Rc = (dual && (ci & 1)) ? Rb : R;
+    vit_chunk(Rc, crops, per_view, r0, mc, vb[dual ? (ci & 1) : 0], cat);
+    if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
+  }
+  if (dual && join_aux(R)) return R.err = 1;
   // bbox MLP per view -> cat[:, 768:1536]; then per-view Linear(1536 -> E) scattered to [n, 2qv, E]
   void* t1 = R.wsT((size_t)per_view * 768);
   void* t2 = R.wsT((size_t)per_view * 768);
@@ -652,36 +691,59 @@ int t5_bias_table(VimaHandle* h, int L, float** out) {
   return 0;
 }
 
-// T5 encoder stack on x fp32 [B*L, 768] (updated in place); result (after final RMSNorm) -> out32 and/or outT
+struct T5Buf { void *hT, *qkv, *ctx, *u; };
+
+void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B, int L,
+              const T5Buf& b, int attn_impl) {
+  const int rows = B * L;
+  R.ln(x, kT5Model, Ly.rms1, nullptr, 1e-6f, 1, rows, kT5Model, nullptr, b.hT);
+  R.linear(b.hT, kT5Model, Ly.qkv, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, b.qkv, 3 * kT5Model);
+  AttnArgs a;
+  a.q = b.qkv; a.ldq = 3 * kT5Model;
+  a.k = R.offT(b.qkv, kT5Model); a.ldk = 3 * kT5Model;
+  a.v = R.offT(b.qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
+  a.out = b.ctx; a.ldo = kT5Model;
+  a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+  a.mode = ATTN_T5;
+  R.attn(a, attn_impl);
+  R.linear(b.ctx, kT5Model, Ly.o, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
+  R.ln(x, kT5Model, Ly.rms2, nullptr, 1e-6f, 1, rows, kT5Model, nullptr, b.hT);
+  R.linear(b.hT, kT5Model, Ly.wi, rows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, kT5FF);
+  R.linear(b.u, kT5FF, Ly.wo, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
+}
+
+// T5 encoder stack on x fp32 [B*L, 768] (updated in place); result (after final RMSNorm) -> out32 and/or outT.
+// Samples are independent, so with dual_stream the batch is split in two halves that run the 12 layers on two streams.
 int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, void* outT) {
   VimaHandle* h = R.h;
-  const int rows = B * L;
   float* table = nullptr;
   if (int e = t5_bias_table(h, L, &table)) return R.err = e;
-  void* hT = R.wsT((size_t)rows * kT5Model);
-  void* qkv = R.wsT((size_t)rows * 3 * kT5Model);
-  void* ctx = R.wsT((size_t)rows * kT5Model);
-  void* u = R.wsT((size_t)rows * kT5FF);
-  if (R.err) return R.err;
-  for (int l = 0; l < kT5Layers; ++l) {
-    auto& Ly = h->t5[l];
-    R.ln(x, kT5Model, Ly.rms1, nullptr, 1e-6f, 1, rows, kT5Model, nullptr, hT);
-    R.linear(hT, kT5Model, Ly.qkv, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * kT5Model);
-    AttnArgs a;
-    a.q = qkv; a.ldq = 3 * kT5Model;
-    a.k = R.offT(qkv, kT5Model); a.ldk = 3 * kT5Model;
-    a.v = R.offT(qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
-    a.out = ctx; a.ldo = kT5Model;
-    a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
-    a.mode = ATTN_T5;
-    R.attn(a, h->attn_impl);
-    R.linear(ctx, kT5Model, Ly.o, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
-    R.ln(x, kT5Model, Ly.rms2, nullptr, 1e-6f, 1, rows, kT5Model, nullptr, hT);
-    R.linear(hT, kT5Model, Ly.wi, rows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, u, kT5FF);
-    R.linear(u, kT5FF, Ly.wo, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
-    if (R.err) return R.err;
+  const bool dual = h->dual_stream && B >= 2;
+  const int nb[2] = {dual ? B - B / 2 : B, dual ? B / 2 : 0};
+  T5Buf buf[2];
+  for (int i = 0; i < (dual ? 2 : 1); ++i) {
+    const size_t rows = (size_t)nb[i] * L;
+    buf[i].hT = R.wsT(rows * kT5Model);
+    buf[i].qkv = R.wsT(rows * 3 * kT5Model);
+    buf[i].ctx = R.wsT(rows * kT5Model);
+    buf[i].u = R.wsT(rows * kT5FF);
   }
-  R.ln(x, kT5Model, h->t5_final, nullptr, 1e-6f, 1, rows, kT5Model, out32, outT);
+  if (R.err) return R.err;
+  Run Rb{h, h->aux};
+  if (dual && fork_aux(R)) return R.err = 1;
+  const long long off1 = (long long)nb[0] * L;      // first row of the second half
+  for (int l = 0; l < kT5Layers; ++l) {
+    t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
+    if (dual) t5_layer(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl);
+    if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
+  }
+  R.ln(x, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[0] * L, kT5Model, out32, outT);
+  if (dual) {
+    Rb.ln(x + off1 * kT5Model, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
+          out32 ? out32 + off1 * kT5Model : nullptr, outT ? R.offT(outT, off1 * kT5Model) : nullptr);
+    if (Rb.err) return R.err = Rb.err;
+    if (join_aux(R)) return R.err = 1;
+  }
   return R.err;
 }
 
@@ -724,6 +786,12 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   h->cfg = *cfg;
   h->device = device;
   h->bf16 = cfg->precision == VIMA_PRECISION_BF16;
+  if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return fail("vima_create: could not create the auxiliary stream/events");
+  }
   *out = h;
   return 0;
 }
@@ -735,6 +803,10 @@ void vima_destroy(VimaHandle* h) {
   for (void* p : h->owned) (void)hipFree(p);
   h->arena.release();
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto e : h->ev_layer) (void)hipEventDestroy(e);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->aux) (void)hipStreamDestroy(h->aux);
   delete h;
 }
 
@@ -793,9 +865,13 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   if (k == "attn_impl") h->attn_impl = (int)value;
   else if (k == "gemm_variant") set_gemm_variant((int)value);
   else if (k == "gemm_tile") set_gemm_tile((int)value);
+  else if (k == "gemm_raster") set_gemm_raster((int)value);
+  else if (k == "gemm_spread") set_gemm_spread((int)value);
+  else if (k == "gemm_prio") set_gemm_prio((int)value);
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
+  else if (k == "dual_stream") h->dual_stream = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
 }
@@ -919,7 +995,13 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
   void* pT = R.wsT((size_t)rp * E);
   void* qn = R.wsT((size_t)rq * E);
   void* Qb = R.wsT((size_t)rq * E);
-  void* KV = R.wsT((size_t)rp * 2 * E);
+  // The prompt K/V projections (components.py:175) depend only on the prompt, not on the token stream: with dual_stream
+  // they are all issued on the auxiliary stream up front (one buffer per layer) and overlap the serial decoder chain.
+  const int NL = h->cfg.xf_n_layers;
+  const bool dual = h->dual_stream != 0;
+  std::vector<void*> KVs(NL);
+  for (int i = 0; i < (dual ? NL : 1); ++i) KVs[i] = R.wsT((size_t)rp * 2 * E);
+  if (!dual) for (int i = 1; i < NL; ++i) KVs[i] = KVs[0];
   void* ctx = R.wsT((size_t)rq * E);
   float* a32 = R.ws<float>((size_t)rq * E);
   void* aT = R.wsT((size_t)rq * E);
@@ -933,12 +1015,28 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
                             h->bf16, R.st), "dec_embed");
   OTHER(R, launch_prompt_pos(prompt, stride_b, stride_l, prompt_mask, h->xpos_emb, h->cfg.xattn_n_positions, pT, B, Lp, E,
                              h->bf16, R.st), "prompt_pos");
+  if (dual) {
+    while ((int)h->ev_layer.size() < NL) {
+      hipEvent_t e;
+      HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->ev_layer.push_back(e);
+    }
+    if (fork_aux(R)) return 1;
+    Run Rb{h, h->aux};
+    for (int i = 0; i < NL; ++i) {
+      Rb.linear(pT, E, h->dec[i].kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KVs[i], 2 * E);
+      if (Rb.err) return Rb.err;
+      HIPCK(hipEventRecord(h->ev_layer[i], h->aux));
+    }
+  }
   for (int i = 0; i < h->cfg.xf_n_layers; ++i) {
     auto& D = h->dec[i];
+    void* KV = KVs[i];
     // ---- XAttention.forward (components.py:158-228)
     R.ln(x32, E, D.xln_g, D.xln_b, 1e-5f, 0, rq, E, nullptr, qn);
     R.linear(qn, E, D.q, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, Qb, E);
-    R.linear(pT, E, D.kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+    if (dual) HIPCK(hipStreamWaitEvent(R.st, h->ev_layer[i], 0));
+    else R.linear(pT, E, D.kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
     AttnArgs a;
     a.q = Qb; a.ldq = E; a.k = KV; a.ldk = 2 * E; a.v = R.offT(KV, E); a.ldv = 2 * E; a.out = ctx; a.ldo = E;
     a.kmask = prompt_mask; a.B = B; a.H = Hx; a.Lq = Lq; a.Lk = Lp; a.D = E / Hx;
@@ -965,6 +1063,7 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
     if (R.err) return R.err;
   }
   OTHER(R, launch_gather_pred(x32, out, T, B, Q, Lq, E, R.st), "gather_pred");
+  if (dual && join_aux(R)) return 1;
   return R.err;
 }
 
