@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (vima_set_option), repeatable")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -155,6 +156,9 @@ def main():
     sd = syn.make_state_dict(cfg, 0)                 # seeded random weights (no checkpoints offline)
     pol = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision=args.precision, device=dev)
     pol.load_state_dict(sd, strict=True)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        pol.set_option(k, int(v))
     B = args.batch
     prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=8, q_per_view=args.qv, seed=1236 + rank), dev)
     obs = syn.to_device(syn.make_obs(1, B, args.qv, seed=1336 + rank), dev)

@@ -22,6 +22,7 @@ def main():
     pol.set_option("gemm_raster", int(os.environ.get("RASTER", "0")))
     pol.set_option("gemm_spread", int(os.environ.get("SPREAD", "0")))
     pol.set_option("gemm_prio", int(os.environ.get("PRIO", "0")))
+    pol.set_option("gemm_epi", int(os.environ.get("EPI", "1")))
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * 0.03
     out = torch.empty(M, N, device="cuda")
@@ -35,7 +36,7 @@ def main():
     torch.cuda.synchronize()
     pr = pol.prof_read()["gemm"]
     ms = pr["ms"] / max(pr["launches"], 1)
-    print(f"M{M} N{N} K{K} tile{tile} raster{os.environ.get('RASTER', '0')} spread{os.environ.get('SPREAD', '0')} prio{os.environ.get('PRIO', '0')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    print(f"M{M} N{N} K{K} tile{tile} raster{os.environ.get('RASTER', '0')} epi{os.environ.get('EPI', '1')} spread{os.environ.get('SPREAD', '0')} prio{os.environ.get('PRIO', '0')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

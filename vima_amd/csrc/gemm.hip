@@ -67,8 +67,14 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_a
 }
 
 // wait for this wave's outstanding LDS-DMA + LDS reads, then workgroup barrier (compiler memory barrier too)
+// The vmcnt wait is inline asm (the DMA is invisible to hipcc); the lgkmcnt wait uses the BUILTIN so that hipcc's own
+// waitcnt scoreboard knows the earlier ds_reads have completed -- otherwise it re-waits for them (and, in order, for
+// every ds_read issued since) in front of the next MFMA, which defeats the prefetch across the barrier.
 __device__ __forceinline__ void wait_all_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)  (vmcnt = 63, expcnt = 7: no wait)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 template <typename T> struct Frag;
@@ -121,6 +127,7 @@ struct GemmDev {
   int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
   int spread;   // LDS-DMA issue: 0 = whole next slice at the top of the current one, 1 = spread over the k-steps
   int prio;     // s_setprio(1) around the MFMA clusters
+  int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
@@ -212,19 +219,32 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
     else glds16(src, smem + off);
   };
 
+  // Software pipeline (2 LDS stages, fragments double-buffered in registers):
+  //   slice kt, steps kk = 0 .. KSTEPS-2 : prefetch fragments of step kk+1 (same stage)      | MFMAs of step kk
+  //   last step                          : vmcnt(0)+lgkmcnt(0), s_barrier  -> every wave has finished READING stage
+  //                                        `cur` and the DMA of slice kt+1 has landed in the other stage; then
+  //                                        issue the DMA of slice kt+2 into `cur`, prefetch the fragments of
+  //                                        slice kt+1 / step 0                                  | MFMAs of the last step
+  // so the barrier and the LDS refill latency after it are covered by the last step's MFMAs (their operands are
+  // already in registers) instead of stalling the matrix pipe at every slice boundary.
 #pragma unroll
   for (int j = 0; j < NP; ++j) issue_piece(0, 0, j);
+  if (nk > 1) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue_piece(1, 1, j);
+  }
   wait_all_and_barrier();
+  Frag<T> fa[2][MI], fw[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) fa[0][mi].load(smem, arow + mi * 32, 0, hi);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) fw[0][ni].load(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
     const char* sA = smem + cur * TL::STAGE_BYTES;
     const char* sW = sA + TL::A_BYTES;
-    Frag<T> fa[2][MI], fw[2][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) fa[0][mi].load(sA, arow + mi * 32, 0, hi);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) fw[0][ni].load(sW, wrow + ni * 32, 0, hi);
+    const char* nA = smem + (cur ^ 1) * TL::STAGE_BYTES;
+    const char* nW = nA + TL::A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
@@ -233,31 +253,31 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
         for (int mi = 0; mi < MI; ++mi) fa[nb][mi].load(sA, arow + mi * 32, kk + 1, hi);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fw[nb][ni].load(sW, wrow + ni * 32, kk + 1, hi);
-      }
-      // the next K-slice's LDS-DMA: p.spread == 0: all pieces right after the first fragment reads, so every piece has
-      // the whole slice of MFMAs to land before the vmcnt(0) at the slice end; p.spread == 1: spread over the k-steps
-      if (more) {
-        if (p.spread) {
+      } else {
+        wait_all_and_barrier();
+        if (kt + 1 < nk) {
 #pragma unroll
-          for (int j = kk * NP / KSTEPS; j < (kk + 1) * NP / KSTEPS; ++j) issue_piece(cur ^ 1, kt + 1, j);
-        } else if (kk == 0) {
+          for (int mi = 0; mi < MI; ++mi) fa[nb][mi].load(nA, arow + mi * 32, 0, hi);
 #pragma unroll
-          for (int j = 0; j < NP; ++j) issue_piece(cur ^ 1, kt + 1, j);
+          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].load(nW, wrow + ni * 32, 0, hi);
+        }
+        if (kt + 2 < nk) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) issue_piece(cur, kt + 2, j);
         }
       }
-      // pin the order: [ds_reads of step kk+1, DMA issue] then [MFMAs of step kk]; without this hipcc re-serialises
+      // pin the order: [ds_reads / DMA issue] then [MFMAs of step kk]; without this hipcc re-serialises
       // read -> wait -> 2 MFMAs on one register set and the LDS latency is exposed
       __builtin_amdgcn_sched_barrier(0);
-      if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
-      if (p.prio) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    wait_all_and_barrier();
   }
+  // (the barrier inside the last slice already guarantees that no wave reads the stage buffers any more, so the LDS
+  // epilogue below may reuse them)
 
   // ------------------------------------------------------------------ epilogue
   // acc[mi][ni][4q+e] = C[m = m0 + wm*MI*32 + mi*32 + l31][n = n0 + wn*NI*32 + ni*32 + 8q + 4hi + e]
@@ -267,6 +287,51 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
   float* out32 = p.out32 ? p.out32 + (long long)z * p.bs32 : nullptr;
   T* outT = p.outT ? reinterpret_cast<T*>(p.outT) + (long long)z * p.bsT : nullptr;
   const int act = ACT >= 0 ? ACT : p.act;
+
+  if constexpr (VEC) {
+    if (p.epi_lds) {
+      // LDS-transposed epilogue. The MFMA layout gives a lane 4 consecutive columns of ONE row, i.e. a store
+      // instruction touches 32 different rows with 16-32 B each (32 partial cache lines per instruction: the write
+      // path, not HBM, then bounds the epilogue, ~7 us per 256x256 tile). Each wave therefore bounces its
+      // 32-row x 64-column slabs through a private 16 KiB LDS region (free after the main loop) and finishes the
+      // epilogue row-contiguously: 16 lanes cover one 64-column row segment, so every global access (gate `mul`,
+      // residual, fp32 / bf16 stores) is a full 128/256-byte line.
+      static_assert(NI == 2, "LDS epilogue assumes a 64-column wave tile");
+      constexpr int LDE = NI * 32 + 4;                      // padded fp32 row stride: conflict-free ds_write_b128
+      float* stage = reinterpret_cast<float*>(smem + w * 16384);
+      const int rr = lane >> 4, cc = (lane & 15) * 4;
+      const int n = n0 + wn * (NI * 32) + cc;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = ni * 32 + 8 * q + 4 * hi;
+            float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+            const int nb = n0 + wn * (NI * 32) + nl;
+            if (bias && nb < p.N) { const float4 b = load4(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+            *reinterpret_cast<float4*>(stage + l31 * LDE + nl) = v;
+          }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int r = it * 4 + rr;
+          float4 v = *reinterpret_cast<const float4*>(stage + r * LDE + cc);
+          const int m = m0 + wm * (MI * 32) + mi * 32 + r;
+          if (m < p.M && n < p.N) {
+            long long orow = m;
+            if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
+            if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
+            if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+            if (out32) store4(out32 + orow * p.ld32 + n, v);
+            if (outT) store4(outT + orow * p.ldT + n, v);
+          }
+        }
+      }
+      return;
+    }
+  }
 
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -325,7 +390,7 @@ inline int gemm_variant() {
   if (g_gemm_variant < 0) g_gemm_variant = env_int("VIMA_GEMM_VARIANT", 1) ? 1 : 0;
   return g_gemm_variant;
 }
-int g_gemm_spread = -1, g_gemm_prio = -1;
+int g_gemm_spread = -1, g_gemm_prio = -1, g_gemm_epi = -1;
 inline int env_cached(const char* name, int& cache, int dflt) {
   if (cache < 0) cache = env_int(name, dflt);
   return cache;
@@ -360,8 +425,9 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.ntiles = (a.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
   d.raster = gemm_raster();
-  d.spread = env_cached("VIMA_GEMM_SPREAD", g_gemm_spread, 0);
+  d.spread = env_cached("VIMA_GEMM_SPREAD", g_gemm_spread, 1);
   d.prio = env_cached("VIMA_GEMM_PRIO", g_gemm_prio, 0);
+  d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1);
   {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
     const long long panel = (long long)TL::BN * a.K * (long long)sizeof(T);
     long long ng = (3LL << 19) / (panel > 0 ? panel : 1);
@@ -426,6 +492,7 @@ void set_gemm_tile(int v) { g_gemm_tile = v; }
 void set_gemm_raster(int v) { g_gemm_raster = v; }
 void set_gemm_spread(int v) { g_gemm_spread = v; }
 void set_gemm_prio(int v) { g_gemm_prio = v; }
+void set_gemm_epi(int v) { g_gemm_epi = v; }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? KCfg<bf16_t>::BK : KCfg<float>::BK; }
 
 }  // namespace vima

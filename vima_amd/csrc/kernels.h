@@ -35,6 +35,7 @@ int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin
 void set_gemm_raster(int v);        // tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
 void set_gemm_spread(int v);        // LDS-DMA issue placement (0 top of slice, 1 spread over k-steps)
+void set_gemm_epi(int v);           // 1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
 void set_gemm_prio(int v);          // s_setprio(1) around MFMA clusters
 void set_gemm_tile(int v);          // 0 = auto, 1 = force 128x128 tiles, 2 = force 256x256 tiles (bf16)
 
