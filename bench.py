@@ -191,7 +191,29 @@ def main():
     assert out.shape == (B * world, 700) and bool(torch.isfinite(out).all())
     ms_per_step = dt / args.steps * 1e3
 
-    # ---- per-class kernel time (HIP events on the launch stream), same workload, outside the timed region
+    # ---- WARM step (prompt tokens reused: obs ViT + decoder + action head), timed the same way, reported as an extra
+    ptok_c, pmask_c = pol.forward_prompt_assembly(prompts)
+
+    def warm_step():
+        otok, omask = pol.forward_obs_token(obs)
+        pred = pol.forward(otok, omask, None, ptok_c, pmask_c)
+        return pol.action_logits(pred[-1])
+
+    warm_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        warm_step()
+    sync()
+    warm_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
+    # ---- per-class kernel time (HIP events on the launch stream), same workload, outside the timed region. The
+    # two-stream software pipelining is switched off for this pass so that kernels do not overlap each other and the
+    # event-bracketed durations are those of the kernels alone (what rocprofv3 --kernel-trace reports for the
+    # committed profile, which is taken with --opt dual_stream=0 for the same reason).
+    pol.set_option("dual_stream", 0)
+    step()
+    torch.cuda.synchronize(dev)
     pol.prof_enable(True)
     step()
     torch.cuda.synchronize(dev)
@@ -211,6 +233,9 @@ def main():
         "other_ms_per_step": round(prof["other"]["ms"], 3),
         "whole_step_tflops": round(B * cold / (ms_per_step * 1e-3) / 1e12, 2),
         "whole_step_frac": round(B * cold / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+        "note": "achieved/avg_launch_us: HIP events around every GEMM launch in a separate pass with dual_stream=0; "
+                "whole_step_*: 49.09 TFLOP algorithmic numerator over the timed wall clock (last ViT block is computed for "
+                "the cls token only -- executed GEMM FLOPs are ~6 % below the algorithmic count)",
     }
 
     cpu_baseline = None
@@ -227,7 +252,8 @@ def main():
                                    f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [8 words + 1 image]), {Q} object tokens/obs, T=1",
                        "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}",
                        "samples_per_s": round(world * B * args.steps / dt, 1),
-                       "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2)},
+                       "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),
+                       "warm_ms_per_step": round(warm_ms, 3), "warm_steps_per_s": round(world * 1e3 / warm_ms, 2)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

@@ -35,6 +35,18 @@ def main():
         _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, 0, p(out), pol._stream()))
     torch.cuda.synchronize()
     pr = pol.prof_read()["gemm"]
+    if os.environ.get("STAMPS"):
+        nblk = ((M + 255) // 256 + 7) // 8 * 8 * ((N + 255) // 256) if tile == 2 else ((M + 127) // 128 + 7) // 8 * 8 * ((N + 127) // 128)
+        dbg = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+        pol.set_option("gemm_dbg_ptr", dbg.data_ptr())
+        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, 0, p(out), pol._stream()))
+        torch.cuda.synchronize()
+        pol.set_option("gemm_dbg_ptr", 0)
+        d = dbg.view(-1, 4).cpu().double()
+        d = d[d[:, 3] > 0]
+        t = d - d[:, :1]
+        print(f"  stamps over {d.shape[0]} workgroups (shader clocks): prologue {t[:, 1].mean():.0f}  main loop {(t[:, 2] - t[:, 1]).mean():.0f}  "
+              f"epilogue {(t[:, 3] - t[:, 2]).mean():.0f}  total {t[:, 3].mean():.0f}; kernel span {(d[:, 3].max() - d[:, 0].min()):.0f}")
     ms = pr["ms"] / max(pr["launches"], 1)
     print(f"M{M} N{N} K{K} tile{tile} raster{os.environ.get('RASTER', '0')} epi{os.environ.get('EPI', '1')} spread{os.environ.get('SPREAD', '0')} prio{os.environ.get('PRIO', '0')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
 

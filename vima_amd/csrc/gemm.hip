@@ -30,7 +30,6 @@ namespace vima {
 
 namespace {
 
-constexpr int ROW_BYTES = 128;                 // bytes of K per tile row
 #ifndef VIMA_GEMM_INTERLEAVE_DMA
 #define VIMA_GEMM_INTERLEAVE_DMA 1
 #endif
@@ -40,29 +39,35 @@ constexpr int ROW_BYTES = 128;                 // bytes of K per tile row
 constexpr bool kDephase = VIMA_GEMM_DEPHASE != 0;   // waves sharing a SIMD prefetch fragments at different points of a step
 constexpr bool kInterleaveDma = VIMA_GEMM_INTERLEAVE_DMA != 0;   // DMA pieces issued between the MFMAs of the last k-step
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int RB_, int NS_>
 struct Tile {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int RB = RB_;                 // bytes of K per tile row (one K-slice): 128 or 64
+  static constexpr int NS = NS_;                 // LDS stages
+  static constexpr int CPR = RB / 16;            // 16-B chunks per row
   static constexpr int NW = WM * WN;             // waves
   static constexpr int THREADS = NW * 64;
   static constexpr int MI = BM / WM / 32;        // 32x32 MFMA tiles per wave along m
   static constexpr int NI = BN / WN / 32;        // ... along n
-  static constexpr int PA = BM / 8 / NW;         // 1-KiB LDS-DMA pieces (8 rows) per wave for the A tile
-  static constexpr int PW = BN / 8 / NW;
-  static constexpr int A_BYTES = BM * ROW_BYTES;
-  static constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-  static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+  static constexpr int PA = BM * RB / 1024 / NW; // 1-KiB LDS-DMA pieces per wave for the A tile of one K-slice
+  static constexpr int PW = BN * RB / 1024 / NW;
+  static constexpr int A_BYTES = BM * RB;
+  static constexpr int STAGE_BYTES = (BM + BN) * RB;
+  static constexpr int SMEM_BYTES = NS * STAGE_BYTES;
   // L2 prefetch of the A stream with 4-byte LDS-DMA touches, 2 slices ahead of the DMA. Measured on MI355X: -3 % (the
   // loop is not bound by the HBM latency of the A stream although a cache-resident A runs +25 %), so it is compiled out.
   static constexpr bool PREFETCH = false;
   static constexpr int SMEM_ALLOC = SMEM_BYTES + (PREFETCH ? NW * 256 : 0);
 };
-using TileS = Tile<128, 128, 2, 2>;
-using TileL = Tile<256, 256, 2, 4>;
+using TileS = Tile<128, 128, 2, 2, 128, 2>;   // 64 KiB, 2 workgroups / CU
+using TileL = Tile<256, 256, 2, 4, 128, 2>;   // 128 KiB, 1 workgroup / CU, 8 waves
+using TileM = Tile<256, 128, 2, 2, 64, 3>;    // 72 KiB, 2 workgroups / CU, 4 waves of 128x64, 3-deep ring of 32-wide slices
+
+template <int RB> __device__ __forceinline__ int swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
 template <typename T> struct KCfg;
-template <> struct KCfg<bf16_t> { static constexpr int BK = 64; static constexpr int EPC = 8; };  // elems / 16-B chunk
-template <> struct KCfg<float> { static constexpr int BK = 32; static constexpr int EPC = 4; };
+template <> struct KCfg<bf16_t> { static constexpr int EPC = 8; };  // elems / 16-B chunk
+template <> struct KCfg<float> { static constexpr int EPC = 4; };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -80,15 +85,6 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_a
 }
 
 // wait for this wave's outstanding LDS-DMA + LDS reads, then workgroup barrier (compiler memory barrier too)
-// 4-byte LDS-DMA used purely as an L2 PREFETCH: lane i touches one cache line of a future A slice; the 256 B that land
-// in a scratch LDS area are never read. (gfx950 has no prefetch instruction; a VGPR-destination load hidden in asm could
-// be clobbered by register reuse, an LDS destination cannot.)
-__device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-}
-
 // The vmcnt wait is inline asm (the DMA is invisible to hipcc); the lgkmcnt wait uses the BUILTIN so that hipcc's own
 // waitcnt scoreboard knows the earlier ds_reads have completed -- otherwise it re-waits for them (and, in order, for
 // every ds_read issued since) in front of the next MFMA, which defeats the prefetch across the barrier.
@@ -98,30 +94,22 @@ __device__ __forceinline__ void wait_all_and_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-// same, but ONE younger VMEM op (the L2-prefetch DMA issued after the slice's DMA pieces) may stay in flight:
-// VMEM loads retire in order, so vmcnt(1) still guarantees that every DMA piece has landed
-__device__ __forceinline__ void wait_all_but_one_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
   uint4 v;
-  __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
+  template <int RB> __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
     const int c = kk * 2 + hi;
-    v = *reinterpret_cast<const uint4*>(tile + r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4));
+    v = *reinterpret_cast<const uint4*>(tile + r * RB + ((c ^ swz<RB>(r)) << 4));
   }
 };
 template <> struct Frag<float> {
   float4 v0, v1;
-  __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
+  template <int RB> __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
+    static_assert(RB == 128, "fp32 operands use 128-byte K-slices");
     const int c = kk * 4 + hi * 2;
-    const int s = (r >> 1) & 7;
-    v0 = *reinterpret_cast<const float4*>(tile + r * ROW_BYTES + ((c ^ s) << 4));
-    v1 = *reinterpret_cast<const float4*>(tile + r * ROW_BYTES + (((c + 1) ^ s) << 4));
+    const int sw = swz<RB>(r);
+    v0 = *reinterpret_cast<const float4*>(tile + r * RB + ((c ^ sw) << 4));
+    v1 = *reinterpret_cast<const float4*>(tile + r * RB + (((c + 1) ^ sw) << 4));
   }
 };
 
@@ -158,16 +146,19 @@ struct GemmDev {
   int spread;   // LDS-DMA issue: 0 = whole next slice at the top of the current one, 1 = spread over the k-steps
   int prio;     // s_setprio(1) around the MFMA clusters
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
+  long long* dbg;   // optional: 4 shader-clock stamps per workgroup (start, main loop start, main loop end, end)
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
 template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS>
 __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK = KCfg<T>::BK;
+  constexpr int RB = TL::RB, NS = TL::NS, CPR = TL::CPR;
+  constexpr int BK = RB / (int)sizeof(T);
   constexpr int EPC = KCfg<T>::EPC;
   constexpr int KSTEPS = BK / 16;
   constexpr int MI = TL::MI, NI = TL::NI, NW = TL::NW;
+  static_assert(KSTEPS >= 2 && (KSTEPS % 2) == 0, "fragment double buffer assumes an even number of k-steps");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -204,23 +195,27 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
 
   const T* A = reinterpret_cast<const T*>(p.A) + (long long)z * p.bsA;
   const T* W = reinterpret_cast<const T*>(p.W) + (long long)z * p.bsW;
+  auto stamp = [&](int slot) {
+    if (p.dbg && tid == 0) p.dbg[(long long)blockIdx.x * 4 + slot] = (long long)__builtin_readcyclecounter();
+  };
+  stamp(0);
 
-  // per-lane source pointers of this wave's LDS-DMA pieces of one K-slice (piece = 8 tile rows = 1 KiB)
+  // per-lane source pointers of this wave's LDS-DMA pieces of one K-slice (piece = 1 KiB = 1024/RB tile rows)
   const T* srcA[TL::PA];
   const T* srcW[TL::PW];
 #pragma unroll
   for (int i = 0; i < TL::PA; ++i) {
     const int s = (i * NW + w) * 64 + lane;
-    const int r = s >> 3, pp = s & 7;
-    const int c = pp ^ ((r >> 1) & 7);
+    const int r = s / CPR, pp = s % CPR;
+    const int c = pp ^ swz<RB>(r);
     int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
     srcA[i] = A + (long long)ra * p.lda + c * EPC;
   }
 #pragma unroll
   for (int i = 0; i < TL::PW; ++i) {
     const int s = (i * NW + w) * 64 + lane;
-    const int r = s >> 3, pp = s & 7;
-    const int c = pp ^ ((r >> 1) & 7);
+    const int r = s / CPR, pp = s % CPR;
+    const int c = pp ^ swz<RB>(r);
     int rw = n0 + r; rw = rw < p.N ? rw : p.N - 1;
     srcW[i] = W + (long long)rw * p.ldw + c * EPC;
   }
@@ -249,124 +244,109 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
     else glds16(src, smem + off);
   };
 
-  // L2 prefetch of the A stream (TileL): every A cache line is needed by this workgroup exactly once, so with a single
-  // slice of DMA in flight per CU the loop would run at HBM latency (measured: +25-30 % when A is cache resident).
-  // Each wave touches, PF_DIST slices ahead of the DMA, the 64 lines (rows) of a future slice with a 4-byte LDS-DMA.
-  constexpr bool PF = TL::PREFETCH && ASMLDS;
-  constexpr int PF_DIST = 2;
-  const T* pf_src = nullptr;
-  if constexpr (PF) {
-    int rp = m0 + (w & 3) * 64 + lane;
-    rp = rp < p.M ? rp : p.M - 1;
-    pf_src = A + (long long)rp * p.lda;
-  }
-  const unsigned pf_lds = smem_base + TL::SMEM_BYTES + w * 256;
-  int pf_pending = 0;
-  if constexpr (PF) {   // the slices right behind the prologue DMA
-    if (2 < nk) glds4_asm(pf_src + 2 * BK, pf_lds);
-    if (3 < nk) glds4_asm(pf_src + 3 * BK, pf_lds);
-  }
-
-  // Software pipeline (2 LDS stages, fragments double-buffered in registers):
+  // Software pipeline (NS LDS stages in a ring, fragments double-buffered in registers):
   //   slice kt, steps kk = 0 .. KSTEPS-2 : prefetch fragments of step kk+1 (same stage)      | MFMAs of step kk
-  //   last step                          : vmcnt(0)+lgkmcnt(0), s_barrier  -> every wave has finished READING stage
-  //                                        `cur` and the DMA of slice kt+1 has landed in the other stage; then
-  //                                        issue the DMA of slice kt+2 into `cur`, prefetch the fragments of
-  //                                        slice kt+1 / step 0                                  | MFMAs of the last step
-  // so the barrier and the LDS refill latency after it are covered by the last step's MFMAs (their operands are
-  // already in registers) instead of stalling the matrix pipe at every slice boundary.
+  //   last step                          : counted vmcnt + lgkmcnt(0), s_barrier -> every wave has finished READING
+  //                                        stage kt % NS and the DMA of slice kt+1 has landed; then prefetch the
+  //                                        fragments of slice kt+1 / step 0 and issue the DMA of slice kt+NS into the
+  //                                        stage just freed, one piece between two MFMAs   | MFMAs of the last step
+  // so the barrier, the LDS refill latency after it and the VMEM issue are covered by the last step's MFMAs (whose
+  // operands are already in registers). VMEM loads retire in order, so `vmcnt(n * NP)` = "all but the n youngest slices".
+  auto wait_slices_and_barrier = [&](int younger) {   // `younger` slices of DMA may stay in flight (wave-uniform)
+    if constexpr (ASMLDS) {
+      if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NP) : "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) via the builtin: keeps hipcc's scoreboard exact
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      wait_all_and_barrier();
+    }
+  };
+  static_assert(NS == 2 || NS == 3, "ring depth");
+  const int npro = nk < NS ? nk : NS;
+  for (int t = 0; t < npro; ++t) {
 #pragma unroll
-  for (int j = 0; j < NP; ++j) issue_piece(0, 0, j);
-  if (nk > 1) {
-#pragma unroll
-    for (int j = 0; j < NP; ++j) issue_piece(1, 1, j);
+    for (int j = 0; j < NP; ++j) issue_piece(t, t, j);
   }
-  wait_all_and_barrier();
+  wait_slices_and_barrier(npro - 1);   // start as soon as slice 0 has landed
+  stamp(1);
   Frag<T> fa[2][MI], fw[2][NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) fa[0][mi].load(smem, arow + mi * 32, 0, hi);
+  for (int mi = 0; mi < MI; ++mi) fa[0][mi].template load<RB>(smem, arow + mi * 32, 0, hi);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) fw[0][ni].load(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
-  // The two waves that share a SIMD (w and w + NW/2) run the SAME instruction stream in lock step after every barrier;
-  // if both fetch fragments at the same moment the matrix pipe idles, then both compete for it. The second half of
-  // the waves therefore issues its fragment prefetch in the MIDDLE of each step's MFMAs instead of in front of them.
+  for (int ni = 0; ni < NI; ++ni) fw[0][ni].template load<RB>(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
+  // The two waves that share a SIMD (w and w + NW/2 of an 8-wave workgroup) run the SAME instruction stream in lock
+  // step after every barrier; if both fetch fragments at the same moment the matrix pipe idles, then both compete
+  // for it. The second half of the waves therefore issues its fragment prefetch in the MIDDLE of each step's MFMAs.
   auto main_loop = [&](auto late_tag) {
-  constexpr bool LATE = decltype(late_tag)::value;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const char* sA = smem + cur * TL::STAGE_BYTES;
-    const char* sW = sA + TL::A_BYTES;
-    const char* nA = smem + (cur ^ 1) * TL::STAGE_BYTES;
-    const char* nW = nA + TL::A_BYTES;
+    constexpr bool LATE = decltype(late_tag)::value;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nxt = cur + 1 == NS ? 0 : cur + 1;
+      const char* sA = smem + cur * TL::STAGE_BYTES;
+      const char* sW = sA + TL::A_BYTES;
+      const char* nA = smem + nxt * TL::STAGE_BYTES;
+      const char* nW = nA + TL::A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-      const int cb = kk & 1, nb = cb ^ 1;
-      if (kk + 1 < KSTEPS) {   // prefetch the next step's fragments while this step's MFMAs run
-        if constexpr (LATE) {
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int cb = kk & 1, nb = cb ^ 1;
+        if (kk + 1 < KSTEPS) {   // prefetch the next step's fragments while this step's MFMAs run
+          if constexpr (LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MI / 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
+          // pin the order: [ds_reads] then [MFMAs]; without this hipcc re-serialises read -> wait -> 2 MFMAs
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mi = 0; mi < MI / 2; ++mi)
+          for (int mi = (LATE ? MI / 2 : 0); mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
           __builtin_amdgcn_sched_barrier(0);
-        }
+        } else {
+          // slices issued so far: up to min(nk-1, kt+NS-1); younger than kt+1 may stay in flight
+          int last = kt + NS - 1;
+          last = last < nk - 1 ? last : nk - 1;
+          wait_slices_and_barrier(last - (kt + 1));
+          if (kt + 1 < nk) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[nb][mi].load(sA, arow + mi * 32, kk + 1, hi);
+            for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(nA, arow + mi * 32, 0, hi);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fw[nb][ni].load(sW, wrow + ni * 32, kk + 1, hi);
-      } else {
-        if (PF && pf_pending) wait_all_but_one_and_barrier();
-        else wait_all_and_barrier();
-        pf_pending = 0;
-        if (kt + 1 < nk) {
+            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(nW, wrow + ni * 32, 0, hi);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // the DMA pieces of slice kt+NS go into the stage just freed, ONE BY ONE BETWEEN the MFMAs
+          constexpr int PPM = (NP + MI * NI - 1) / (MI * NI);
+          const bool more = kt + NS < nk;
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) fa[nb][mi].load(nA, arow + mi * 32, 0, hi);
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].load(nW, wrow + ni * 32, 0, hi);
-        }
-        if (!kInterleaveDma && kt + 2 < nk) {
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) {
 #pragma unroll
-          for (int j = 0; j < NP; ++j) issue_piece(cur, kt + 2, j);
-        }
-      }
-      // pin the order: [ds_reads / DMA issue] then [MFMAs of step kk]; without this hipcc re-serialises
-      // read -> wait -> 2 MFMAs on one register set and the LDS latency is exposed
-      __builtin_amdgcn_sched_barrier(0);
-      if (kInterleaveDma && kk + 1 == KSTEPS) {
-        // last step: the DMA pieces of slice kt+2 are issued ONE BY ONE BETWEEN the MFMAs (each VMEM issue is then
-        // covered by a matrix instruction already in flight instead of delaying the first MFMA after the barrier)
-        constexpr int PPM = (NP + MI * NI - 1) / (MI * NI);
-        const bool more2 = kt + 2 < nk;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more2) {
-#pragma unroll
-              for (int j = (mi * NI + ni) * PPM; j < (mi * NI + ni + 1) * PPM && j < NP; ++j) issue_piece(cur, kt + 2, j);
+                for (int j = (mi * NI + ni) * PPM; j < (mi * NI + ni + 1) * PPM && j < NP; ++j) issue_piece(cur, kt + NS, j);
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        if constexpr (PF) {   // youngest VMEM op of this slice: prefetch for the DMA issued PF_DIST slices later
-          if (kt + 2 + PF_DIST < nk && more2) {
-            glds4_asm(pf_src + (kt + 2 + PF_DIST) * BK, pf_lds);
-            pf_pending = 1;
-          }
         }
-      } else {
-#pragma unroll
-        for (int mi = (LATE ? MI / 2 : 0); mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
-  }
   };
-  if (kDephase && w >= NW / 2) main_loop(std::true_type{});
+  if (kDephase && NW == 8 && w >= NW / 2) main_loop(std::true_type{});
   else main_loop(std::false_type{});
+  stamp(2);
   // (the barrier inside the last slice already guarantees that no wave reads the stage buffers any more, so the LDS
   // epilogue below may reuse them)
 
@@ -389,7 +369,8 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
       // residual, fp32 / bf16 stores) is a full 128/256-byte line.
       static_assert(NI == 2, "LDS epilogue assumes a 64-column wave tile");
       constexpr int LDE = NI * 32 + 4;                      // padded fp32 row stride: conflict-free ds_write_b128
-      float* stage = reinterpret_cast<float*>(smem + w * 16384);
+      static_assert(TL::SMEM_BYTES / NW >= 32 * LDE * 4, "per-wave LDS slab for the epilogue");
+      float* stage = reinterpret_cast<float*>(smem + w * (TL::SMEM_BYTES / NW));
       const int rr = lane >> 4, cc = (lane & 15) * 4;
       const int n = n0 + wn * (NI * 32) + cc;
 #pragma unroll
@@ -420,6 +401,7 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
           }
         }
       }
+      stamp(3);
       return;
     }
   }
@@ -471,7 +453,7 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
 
 // 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin (TileS only). Override with VIMA_GEMM_VARIANT.
 int g_gemm_variant = -1;
-int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL (bf16 only)
+int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL, 3 force TileM (bf16 only)
 int g_gemm_raster = -1; // see GemmDev::raster
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -482,6 +464,7 @@ inline int gemm_variant() {
   return g_gemm_variant;
 }
 int g_gemm_spread = -1, g_gemm_prio = -1, g_gemm_epi = -1;
+long long* g_gemm_dbg = nullptr;
 inline int env_cached(const char* name, int& cache, int dflt) {
   if (cache < 0) cache = env_int(name, dflt);
   return cache;
@@ -519,6 +502,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.spread = env_cached("VIMA_GEMM_SPREAD", g_gemm_spread, 1);
   d.prio = env_cached("VIMA_GEMM_PRIO", g_gemm_prio, 0);
   d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1);
+  d.dbg = g_gemm_dbg;
   {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
     const long long panel = (long long)TL::BN * a.K * (long long)sizeof(T);
     long long ng = (3LL << 19) / (panel > 0 ? panel : 1);
@@ -539,7 +523,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
 
 template <typename T>
 int launch_t(const GemmArgs& a, hipStream_t st) {
-  constexpr int BK = KCfg<T>::BK;
+  constexpr int BK = 128 / (int)sizeof(T);   // K granularity of the widest K-slice (TileS / TileL)
   if (a.M <= 0 || a.N <= 0) return 0;
   if (a.K <= 0 || a.K % BK != 0) return (int)hipErrorInvalidValue;
   // LDS-DMA reads 16-B chunks: rows must start 16-B aligned
@@ -571,7 +555,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 224) && waste < 1.15;
     if (gemm_tile() == 1) large = false;
-    if (gemm_tile() == 2) large = v;
+    if (gemm_tile() == 2 || gemm_tile() == 3) large = v;
+    if (large && gemm_tile() == 3) return launch_tile<T, TileM, true>(d, a, v, st);
     if (large) return launch_tile<T, TileL, true>(d, a, v, st);
   }
   if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);
@@ -589,6 +574,7 @@ void set_gemm_raster(int v) { g_gemm_raster = v; }
 void set_gemm_spread(int v) { g_gemm_spread = v; }
 void set_gemm_prio(int v) { g_gemm_prio = v; }
 void set_gemm_epi(int v) { g_gemm_epi = v; }
-int gemm_k_multiple(bool is_bf16) { return is_bf16 ? KCfg<bf16_t>::BK : KCfg<float>::BK; }
+void set_gemm_dbg(long long* p) { g_gemm_dbg = p; }
+int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
 
 }  // namespace vima

@@ -869,6 +869,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_spread") set_gemm_spread((int)value);
   else if (k == "gemm_prio") set_gemm_prio((int)value);
   else if (k == "gemm_epi") set_gemm_epi((int)value);
+  else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
