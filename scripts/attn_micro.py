@@ -1,0 +1,42 @@
+"""T5 attention microbenchmark through the C ABI (vima_op_attention): python scripts/attn_micro.py B H L D [iters]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vima_amd import _lib                      # noqa: E402
+from vima_amd.policy import VIMAPolicy         # noqa: E402
+
+
+def main():
+    B, H, L, D = (int(x) for x in sys.argv[1:5])
+    iters = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    mode = int(os.environ.get("MODE", "0"))
+    Lq = int(os.environ.get("LQ", str(L)))
+    pol = VIMAPolicy(embed_dim=256, xf_n_layers=1, sattn_n_heads=8, xattn_n_heads=8, precision="bf16", device="cuda:0")
+    pol._ensure_handle()
+    q = torch.randn(B, Lq, H, D, device="cuda") * 0.4
+    k = torch.randn(B, L, H, D, device="cuda") * 0.4
+    v = torch.randn(B, L, H, D, device="cuda")
+    mask = torch.ones(B, L, dtype=torch.bool, device="cuda")
+    rb = torch.randn(H, 2 * L - 1, device="cuda")
+    out = torch.empty(B, Lq, H, D, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    scale = 1.0 if mode == 0 else D ** -0.5
+    for _ in range(2):
+        _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 1, p(out), pol._stream()))
+    torch.cuda.synchronize()
+    pol.prof_enable(True)
+    for _ in range(iters):
+        _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 1, p(out), pol._stream()))
+    torch.cuda.synchronize()
+    pr = pol.prof_read()["attention"]
+    ms = pr["ms"] / max(pr["launches"], 1)
+    print(f"attn mode{mode} B{B} H{H} Lq{Lq} Lk{L} D{D}: {ms:.3f} ms = {4.0 * B * H * Lq * L * D / ms / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()

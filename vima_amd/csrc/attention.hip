@@ -389,7 +389,6 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
   bf16_t* vt_base = reinterpret_cast<bf16_t*>(smem4 + 2 * KS_BYTES);   // [2][D][VT4_STRIDE]
   float* madd = reinterpret_cast<float*>(smem4 + 2 * KS_BYTES + 2 * VT_BYTES);   // [nt*64]
   const int nt = (p.Lk + 63) / 64;
-  float* btab = madd + nt * 64;                                // [2*Lk-1] (T5 only)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -407,14 +406,31 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
 
   // ---- workgroup-wide tables
-  for (int j = tid; j < nt * 64; j += 256) {
-    float v = -INFINITY;                                       // keys beyond Lk never contribute
+  // madd[j]: additive key mask (0 / finfo.min; -inf beyond Lk so padded keys never contribute)
+  // tflag[t]: 1 when tile t needs madd (a masked or out-of-range key), else the adds are skipped for the whole tile
+  // btab (T5): relative-position bias indexed by (key - query) + boff, zero-padded so that every index a lane of this
+  //            workgroup can form (including padded queries / keys) is in range -> no clamps in the inner loop
+  int* tflag = reinterpret_cast<int*>(madd + nt * 64);
+  float* btab = reinterpret_cast<float*>(tflag + ((nt + 3) & ~3));
+  const int qpad = nq * 128, kpad = nt * 64;
+  const int boff = qpad - 1;                                   // index = key - qi + boff in [0, qpad + kpad - 2]
+  for (int j = tid; j < kpad; j += 256) {
+    float v = -INFINITY;
     if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lk + j]) ? -FLT_MAX : 0.0f;
     madd[j] = v;
   }
   if (MODE == ATTN_T5) {
     const float* rb = p.relbias + (long long)h * (2 * p.Lk - 1);
-    for (int j = tid; j < 2 * p.Lk - 1; j += 256) btab[j] = rb[j];
+    for (int j = tid; j < qpad + kpad - 1; j += 256) {
+      const int delta = j - boff;                              // key - query
+      btab[j] = (delta > -p.Lk && delta < p.Lk) ? rb[delta + p.Lk - 1] : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (tid < nt) {
+    int f = 0;
+    for (int j = 0; j < 64; ++j) f |= (madd[tid * 64 + j] != 0.0f) ? 1 : 0;
+    tflag[tid] = f;
   }
 
   const int qrow = qi < p.Lq ? qi : p.Lq - 1;
@@ -483,57 +499,71 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s[sub], 0, 0, 0);
       }
     }
-    // ---- scores -> probabilities
+    // ---- scores -> probabilities (fp32). The per-element work is kept minimal: one bias read at a lane-constant base
+    // + immediate offset, the key-mask add only in tiles that contain a masked / padded key, exp2 with the log2(e)
+    // factor folded into one FMA, and the O^T rescale only when some row maximum of the wave actually moved.
     float x[2][16];
     float mt = -INFINITY;
+    const bool masked_tile = tflag[t] != 0;                    // workgroup-uniform
+    const float* bq = btab + (boff - qi + k0 + 4 * hi);        // T5: bias of key (k0 + 4hi + j) is bq[j]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int key = k0 + sub * 32 + 8 * g + 4 * hi;        // 4 consecutive keys key..key+3 (multiple of 4)
-        const float4 ma = *reinterpret_cast<const float4*>(madd + key);
-        const float mav[4] = {ma.x, ma.y, ma.z, ma.w};
+        const int kl = sub * 32 + 8 * g;                       // key = k0 + kl + 4*hi + e
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float sv = s[sub][4 * g + e];
           float v;
-          if (MODE == ATTN_T5) {
-            int bi = (key + e) - qi + p.Lk - 1;
-            bi = bi < 0 ? 0 : (bi > 2 * p.Lk - 2 ? 2 * p.Lk - 2 : bi);
-            v = sv + (btab[bi] + mav[e]);
-          } else if (MODE == ATTN_CROSS) {
-            v = sv * p.scale + mav[e];
-          } else {
-            v = sv * p.scale;
-            if (key + e > qi) v = -1e4f;
-            v = v + mav[e];
-          }
+          if (MODE == ATTN_T5) v = sv + bq[kl + e];
+          else if (MODE == ATTN_CROSS) v = sv * p.scale;
+          else v = (k0 + kl + 4 * hi + e > qi) ? -1e4f : sv * p.scale;
           x[sub][4 * g + e] = v;
-          mt = fmaxf(mt, v);
         }
       }
     }
+    if (masked_tile) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ma = *reinterpret_cast<const float4*>(madd + k0 + sub * 32 + 8 * g + 4 * hi);
+          // reference order of operations: T5 adds (bias + mask) to the score, the others add the mask last; for the
+          // values involved (0 or -finfo.max / -inf) both orders round identically
+          x[sub][4 * g + 0] += ma.x; x[sub][4 * g + 1] += ma.y; x[sub][4 * g + 2] += ma.z; x[sub][4 * g + 3] += ma.w;
+        }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, x[sub][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = __expf(m_run - m_new);
+    // exp(x - m) = exp2((x - m) * log2 e). (x - m) is formed first: with the reference's finfo.min masks, m itself can be
+    // -finfo.max (fully masked row) and m * log2(e) would overflow.
+    constexpr float kLog2e = 1.4426950408889634f;
     uint32_t pk[2][8];
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __expf(x[sub][r] - m_new), p1 = __expf(x[sub][r + 1] - m_new);
-        const uint32_t u = pack2_bf16(p0, p1);
-        pk[sub][r >> 1] = u;
-        rs += __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u);
+        const float p0 = __builtin_amdgcn_exp2f((x[sub][r] - m_new) * kLog2e);
+        const float p1 = __builtin_amdgcn_exp2f((x[sub][r + 1] - m_new) * kLog2e);
+        pk[sub][r >> 1] = pack2_bf16(p0, p1);
+        rs += p0 + p1;
       }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
+    if (__any(m_new != m_run)) {                               // wave-uniform: some row maximum moved
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+      l_run *= alpha;
 #pragma unroll
-    for (int it = 0; it < OT; ++it)
+      for (int it = 0; it < OT; ++it)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += rs;
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -622,8 +652,9 @@ void set_attn4_min_lq(int v) { g_attn4_min_lq = v; }
 template <int D, int MODE>
 static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   const int nt = (a.Lk + 63) / 64;
-  const size_t sh = 2 * (64 * D * 2) + 2 * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 +
-                    (MODE == ATTN_T5 ? (size_t)(2 * a.Lk) * 4 : 0);
+  const int nq_ = (a.Lq + 127) / 128;
+  const size_t sh = 2 * (64 * D * 2) + 2 * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 + (size_t)((nt + 3) & ~3) * 4 +
+                    (MODE == ATTN_T5 ? (size_t)(nq_ * 128 + nt * 64) * 4 : 0);
   if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
