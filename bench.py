@@ -70,7 +70,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0):
+def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
     """The oracle (torch fp32 port of the reference CPU path) timed on the host cores on a BOUNDED sample of the same
     workload. Thread count is calibrated first (a 256-thread host with a small cgroup quota is slower at 256 threads)."""
     from oracle.vima_oracle import OraclePolicy
@@ -95,14 +95,14 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0):
     orc = OraclePolicy(sd, **cfg.ctor_kwargs())
     t_start = time.perf_counter()
     with torch.no_grad():
-        p1 = syn.make_prompt(1, n_segments=n_seg, words_per_segment=8, q_per_view=qv, seed=1236)
+        p1 = syn.make_prompt(1, n_segments=n_seg, words_per_segment=words, q_per_view=qv, seed=1236)
         o1 = syn.make_obs(1, 1, qv, seed=1336)
         t0 = time.perf_counter()
         orc.cold_step(p1, o1)                                   # warm-up + cost probe at batch 1
         t_b1 = time.perf_counter() - t0
         cb, it, cdt = 1, 1, t_b1
         if t_b1 * (cpu_batch + 1) < budget_s:                   # affordable: time the requested sample batch
-            pc = syn.make_prompt(cpu_batch, n_segments=n_seg, words_per_segment=8, q_per_view=qv, seed=1236)
+            pc = syn.make_prompt(cpu_batch, n_segments=n_seg, words_per_segment=words, q_per_view=qv, seed=1236)
             oc = syn.make_obs(1, cpu_batch, qv, seed=1336)
             it, t1 = 0, time.perf_counter()
             while it < 3 and (time.perf_counter() - t_start) + (time.perf_counter() - t1) / max(it, 1) < budget_s:
@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--model", default="200M")
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--qv", type=int, default=4, help="objects per view (Q = 2*qv object tokens per observation)")
+    ap.add_argument("--words", type=int, default=8, help="words per prompt segment (a segment = words + 1 image)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -149,8 +150,8 @@ def main():
     from vima_amd.policy import VIMAPolicy
 
     Q = 2 * args.qv
-    seg_len = 8 + Q                                  # 8 words + 1 image (Q object tokens) per segment
-    assert args.prompt_len % seg_len == 0, "prompt length must be a multiple of 8 + Q"
+    seg_len = args.words + Q                         # words + 1 image (Q object tokens) per segment
+    assert args.prompt_len % seg_len == 0, "prompt length must be a multiple of words + Q"
     n_seg = args.prompt_len // seg_len
     cfg = syn.config(args.model, xattn_n_positions=max(256, args.prompt_len))
     sd = syn.make_state_dict(cfg, 0)                 # seeded random weights (no checkpoints offline)
@@ -160,7 +161,7 @@ def main():
         k, v = kv.split("=")
         pol.set_option(k, int(v))
     B = args.batch
-    prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=8, q_per_view=args.qv, seed=1236 + rank), dev)
+    prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=args.words, q_per_view=args.qv, seed=1236 + rank), dev)
     obs = syn.to_device(syn.make_obs(1, B, args.qv, seed=1336 + rank), dev)
 
     def step():
@@ -240,7 +241,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(cfg, sd, n_seg, args.qv, args.cpu_batch, B)
+        cpu_baseline = run_cpu_baseline(cfg, sd, n_seg, args.qv, args.cpu_batch, B, words=args.words)
 
     if rank == 0:
         line = {
@@ -249,7 +250,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"VIMA-{args.model} COLD policy forward (prompt assembly ViT+T5, obs ViT, XAttnGPT, action head) "
-                                   f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [8 words + 1 image]), {Q} object tokens/obs, T=1",
+                                   f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [{args.words} words + 1 image]), {Q} object tokens/obs, T=1",
                        "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}",
                        "samples_per_s": round(world * B * args.steps / dt, 1),
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),

@@ -131,7 +131,9 @@ def attn_ref(q, k, v, kmask, relbias, scale, mode):
 
 ATTN_CASES = [(0, 2, 12, 64, 64, 64), (0, 1, 12, 100, 100, 64), (1, 3, 8, 8, 40, 32), (1, 2, 24, 71, 300, 32),
               (2, 2, 8, 9, 9, 32), (2, 3, 24, 71, 71, 32), (1, 2, 4, 5, 33, 64), (2, 1, 4, 40, 40, 64),
-              (0, 2, 12, 300, 300, 64), (0, 1, 3, 512, 512, 64), (2, 2, 4, 200, 200, 32), (1, 2, 4, 130, 65, 64)]
+              (0, 2, 12, 300, 300, 64), (0, 1, 3, 512, 512, 64), (2, 2, 4, 200, 200, 32), (1, 2, 4, 130, 65, 64),
+              # few queries, many keys: the split-key kernel (Lq <= 32, Lk >= 64)
+              (1, 3, 8, 8, 200, 32), (1, 2, 4, 30, 512, 64), (1, 2, 24, 8, 512, 32), (1, 2, 4, 32, 64, 32), (1, 2, 2, 1, 129, 64)]
 
 
 @pytest.mark.parametrize("prec,impl", [("fp32", 0), ("bf16", 0), ("bf16", 1), ("bf16", 4)])

@@ -599,6 +599,209 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
   }
 }
 
+// =============================================================================================== MFMA flash attention, split keys
+// Few queries (Lq <= 32: the cross-attention of one env step has 8, XAttention components.py:184-214), many keys: one
+// workgroup = 4 waves = ONE (batch, head); 128-key tiles are staged cooperatively in LDS (coalesced 16-B loads, next tile
+// prefetched in registers) and each wave takes one 32-key quarter of every tile with its own online-softmax state; the
+// four partial (max, sum, O^T) states are merged through LDS at the end ("flash decoding" inside a workgroup).
+// 4x the parallelism of the one-wave kernel per (batch, head) and no per-lane global loads in the loop.
+constexpr int SPLIT_TK = 128;
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smems[];
+  constexpr int KD = D / 16, OT = D / 32, CPR = D / 8;
+  constexpr int ROWB = D * 2;
+  constexpr int KS_BYTES = SPLIT_TK * ROWB;
+  constexpr int VTS = SPLIT_TK + 4;                            // bf16 elements per V^T row (264 B: conflict-free b64 reads)
+  constexpr int VT_BYTES = D * VTS * 2;
+  constexpr int CH = SPLIT_TK * CPR / 256;                     // 16-B chunks per thread per tile
+  char* ks_base = smems;
+  bf16_t* vt_base = reinterpret_cast<bf16_t*>(smems + 2 * KS_BYTES);
+  float* madd = reinterpret_cast<float*>(smems + 2 * KS_BYTES + 2 * VT_BYTES);
+  const int nt = (p.Lk + SPLIT_TK - 1) / SPLIT_TK;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  // Adjacent heads share 128-byte lines of the K/V rows (a head is 64 B wide at D = 32): workgroups id and id + 8 run
+  // back to back on the same XCD (id % 8), so they are given heads 2k and 2k + 1 and the second one hits in that L2.
+  const int bid = blockIdx.x;
+  const int bh = (((bid >> 4) << 3) + (bid & 7)) * 2 + ((bid >> 3) & 1);
+  if (bh >= p.B * p.H) return;
+  const int h = bh % p.H, b = bh / p.H;
+  const int qi = l31;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q);
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k);
+  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
+
+  for (int j = tid; j < nt * SPLIT_TK; j += 256) {
+    float v = -INFINITY;
+    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lk + j]) ? -FLT_MAX : 0.0f;
+    madd[j] = v;
+  }
+  const int qrow = qi < p.Lq ? qi : p.Lq - 1;
+  bf16x8_t qf[KD];
+#pragma unroll
+  for (int dd = 0; dd < KD; ++dd) {
+    const uint4 u = *reinterpret_cast<const uint4*>(Q + ((long long)b * p.Lq + qrow) * p.ldq + h * D + dd * 16 + hi * 8);
+    qf[dd] = __builtin_bit_cast(bf16x8_t, u);
+  }
+  f32x16_t ot[OT];
+#pragma unroll
+  for (int it = 0; it < OT; ++it)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  uint4 kreg[CH], vreg[CH];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / CPR, c = id % CPR;
+      int row = t * SPLIT_TK + key;
+      row = row < p.Lk ? row : p.Lk - 1;
+      kreg[i] = *reinterpret_cast<const uint4*>(K + ((long long)b * p.Lk + row) * p.ldk + h * D + c * 8);
+      vreg[i] = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lk + row) * p.ldv + h * D + c * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* ks = ks_base + buf * KS_BYTES;
+    bf16_t* vt = vt_base + buf * (D * VTS);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / CPR, c = id % CPR;
+      *reinterpret_cast<uint4*>(ks + key * ROWB + (kswz<D>(key, c) << 4)) = kreg[i];
+      const uint32_t wds[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(c * 8 + 2 * e) * VTS + key] = (bf16_t)(wds[e] & 0xffffu);
+        vt[(c * 8 + 2 * e + 1) * VTS + key] = (bf16_t)(wds[e] >> 16);
+      }
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  constexpr float kLog2e = 1.4426950408889634f;
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(t + 1);
+    const char* ks = ks_base + buf * KS_BYTES;
+    const bf16_t* vt = vt_base + buf * (D * VTS);
+    const int kb = t * SPLIT_TK + w * 32;                      // first key of this wave's quarter
+    if (kb < p.Lk) {                                           // wave-uniform: quarter not entirely beyond the keys
+      f32x16_t s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const int row = w * 32 + l31;
+#pragma unroll
+      for (int dd = 0; dd < KD; ++dd) {
+        const uint4 u = *reinterpret_cast<const uint4*>(ks + row * ROWB + (kswz<D>(row, dd * 2 + hi) << 4));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s, 0, 0, 0);
+      }
+      float x[16];
+      float mt = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key = kb + 8 * g + 4 * hi;
+        const float4 ma = *reinterpret_cast<const float4*>(madd + key);
+        const float mav[4] = {ma.x, ma.y, ma.z, ma.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = s[4 * g + e] * p.scale;
+          if (MODE == ATTN_CAUSAL && key + e > qi) v = -1e4f;
+          v = v + mav[e];
+          x[4 * g + e] = v;
+          mt = fmaxf(mt, v);
+        }
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);                    // finite: key kb is in range
+      uint32_t pk[8];
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f((x[r] - m_new) * kLog2e);
+        const float p1 = __builtin_amdgcn_exp2f((x[r + 1] - m_new) * kLog2e);
+        pk[r >> 1] = pack2_bf16(p0, p1);
+        rs += p0 + p1;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+        l_run *= alpha;
+#pragma unroll
+        for (int it = 0; it < OT; ++it)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += rs;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint4 pu;
+        pu.x = pk[half * 4 + 0]; pu.y = pk[half * 4 + 1]; pu.z = pk[half * 4 + 2]; pu.w = pk[half * 4 + 3];
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+        for (int it = 0; it < OT; ++it) {
+          const bf16_t* vr = vt + (it * 32 + l31) * VTS + w * 32 + 16 * half + 4 * hi;
+          const uint2 a0 = *reinterpret_cast<const uint2*>(vr);
+          const uint2 a1 = *reinterpret_cast<const uint2*>(vr + 8);
+          uint4 vu;
+          vu.x = a0.x; vu.y = a0.y; vu.z = a1.x; vu.w = a1.y;
+          ot[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vu), pf, ot[it], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- merge the four partial softmax states (stage buffers are free after the loop's last barrier)
+  constexpr int NV = OT * 16 + 2;
+  float* comb = reinterpret_cast<float*>(smems);               // [4][NV][64]
+  float* mine = comb + (w * NV) * 64 + lane;
+#pragma unroll
+  for (int it = 0; it < OT; ++it)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[(it * 16 + r) * 64] = ot[it][r];
+  mine[(OT * 16) * 64] = m_run;
+  mine[(OT * 16 + 1) * 64] = l_run;
+  __syncthreads();
+  if (w == 0 && qi < p.Lq) {
+    float mw[4], m_all = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mw[j] = comb[(j * NV + OT * 16) * 64 + lane];
+      m_all = fmaxf(m_all, mw[j]);
+    }
+    float sc[4], l_all = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = __builtin_amdgcn_exp2f((mw[j] - m_all) * kLog2e);   // a wave that saw no key has m = -inf -> weight 0
+      l_all += comb[(j * NV + OT * 16 + 1) * 64 + lane] * sc[j];
+    }
+    const float inv = 1.0f / l_all;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + ((long long)b * p.Lq + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc += comb[(j * NV + it * 16 + 4 * g + e) * 64 + lane] * sc[j];
+          o4[e] = acc * inv;
+        }
+        store4(op + it * 32 + 8 * g + 4 * hi, make_float4(o4[0], o4[1], o4[2], o4[3]));
+      }
+  }
+}
+
 inline AttnDev to_dev(const AttnArgs& a) {
   AttnDev d;
   d.q = a.q; d.ldq = a.ldq; d.k = a.k; d.ldk = a.ldk; d.v = a.v; d.ldv = a.ldv; d.out = a.out; d.ldo = a.ldo;
@@ -670,6 +873,27 @@ static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+int g_attn_split = 1;   // use the split-key kernel for Lq <= 32 (cross / short causal attention)
+void set_attn_split(int v) { g_attn_split = v; }
+
+template <int D, int MODE>
+static int launch_split(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
+  const int nt = (a.Lk + SPLIT_TK - 1) / SPLIT_TK;
+  size_t sh = 2 * (SPLIT_TK * D * 2) + 2 * (D * (SPLIT_TK + 4) * 2) + (size_t)nt * SPLIT_TK * 4;
+  const size_t comb = (size_t)4 * (D / 32 * 16 + 2) * 64 * 4;
+  if (sh < comb) sh = comb;
+  if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel<D, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((attn_split_kernel<D, MODE>), dim3((unsigned)(((a.B * a.H + 15) / 16) * 16)), dim3(256), sh, st, d);
+  return (int)hipGetLastError();
+}
+
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
   if (a.D != 32 && a.D != 64) return (int)hipErrorInvalidValue;
@@ -677,6 +901,10 @@ int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
   // 16-byte fragment loads: rows and head offsets must be 16-B aligned
   if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) return (int)hipErrorInvalidValue;
   const AttnDev d = to_dev(a);
+  if (g_attn_split && a.Lq <= 32 && a.mode != ATTN_T5 && a.Lk >= 64) {
+    if (a.D == 32) return a.mode == ATTN_CROSS ? launch_split<32, ATTN_CROSS>(d, a, st) : launch_split<32, ATTN_CAUSAL>(d, a, st);
+    return a.mode == ATTN_CROSS ? launch_split<64, ATTN_CROSS>(d, a, st) : launch_split<64, ATTN_CAUSAL>(d, a, st);
+  }
   if (a.Lq >= g_attn4_min_lq) {
     if (a.D == 32) {
       if (a.mode == ATTN_T5) return launch_mfma4<32, ATTN_T5>(d, a, st);

@@ -96,6 +96,7 @@ struct AttnArgs {
 // generic exact kernel (any T); the MFMA flash kernel (bf16, D in {32,64})
 int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st);
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st);
+void set_attn_split(int v);     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
 void set_attn4_min_lq(int v);   // Lq threshold for the 4-wave LDS-shared flash kernel (below: 1-wave kernel)
 
 }  // namespace vima
