@@ -91,10 +91,14 @@ int vima_t5_encode(VimaHandle* h, const float* x, const uint8_t* mask, int B, in
 /* VIMAPolicy.forward (vima_policy.py:116-159) -> XAttnGPT.forward (xattn_gpt.py:73-139).
  * obs_tok f32 [T,B,Q,E], obs_mask u8 [T,B,Q], act_tok f32 [L_act,B,E] or NULL (L_act in {T-1, T}),
  * prompt f32 element (b,l,e) at prompt[b*stride_b + l*stride_l + e] (so both the [B,Lp,E] buffer and the reference's
- * sequence-first [Lp,B,E] layout can be passed), prompt_mask u8 [B,Lp] -> out f32 [T,B,E] (sequence-first). */
+ * sequence-first [Lp,B,E] layout can be passed), prompt_mask u8 [B,Lp] -> out f32 [T,B,E] (sequence-first).
+ * kv_cache_mode: the per-layer prompt K/V projection (components.py:175) is loop-invariant over the env steps of an
+ * episode. 0 = stateless (recompute, like the reference); 1 = compute it into the handle's
+ * cache and use it; 2 = reuse the cache of the last mode-1 call (same B, Lp; `prompt` is not read). Outputs are
+ * bit-identical in all three modes. */
 int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B,
                 int Q, int L_act, const float* prompt, int64_t stride_b, int64_t stride_l,
-                const uint8_t* prompt_mask, int Lp, float* out, vima_stream_t stream);
+                const uint8_t* prompt_mask, int Lp, int kv_cache_mode, float* out, vima_stream_t stream);
 
 /* VIMAPolicy.forward_action_decoder (vima_policy.py:264-265 -> action_decoder.py:51-52,165-166): tokens f32 [R,E]
  * -> raw logits f32 [R,700] = concat over keys (pose0_position, pose0_rotation, pose1_position, pose1_rotation) of

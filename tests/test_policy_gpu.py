@@ -116,6 +116,37 @@ def test_dual_stream_and_pruning_are_exact():
             assert torch.equal(o[k], outs[0][k]), k
 
 
+def test_prompt_kv_cache_is_exact_and_invalidates():
+    """Cross-step caching of the per-layer prompt K/V: passing the same prompt tensor again reuses
+    the cache and must give bit-identical tokens; an in-place edit of the prompt (version counter) or a new tensor
+    invalidates it; a stateless policy (cache off) agrees bit for bit."""
+    cfg = syn.config("4M")
+    sd = syn.make_state_dict(cfg, 5)
+    pol = loaded_policy(cfg, sd, "bf16")
+    ref = loaded_policy(cfg, sd, "bf16")
+    ref.cache_prompt_kv = False
+    g = torch.Generator().manual_seed(1)
+    B, Lp, Q, E = 3, 40, 4, cfg.embed_dim
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = torch.ones(B, Lp, dtype=torch.bool, device=DEV)
+    steps = []
+    for T in (1, 2, 3):                                    # a growing history like the eval loop (example.py:135-190)
+        otok = torch.randn(T, B, Q, E, generator=g).to(DEV)
+        omask = torch.ones(T, B, Q, dtype=torch.bool, device=DEV)
+        atok = torch.randn(T - 1, B, E, generator=g).to(DEV) if T > 1 else None
+        a = pol.forward(otok, omask, atok, ptok, pmask)    # T=1 builds the cache, T=2,3 reuse it
+        b = ref.forward(otok, omask, atok, ptok, pmask)
+        assert torch.equal(a, b), T
+        steps.append((otok, omask, atok, a))
+    otok, omask, atok, last = steps[-1]
+    ptok.mul_(1.5)                                         # in-place edit -> stale cache must not be used
+    a = pol.forward(otok, omask, atok, ptok, pmask)
+    assert torch.equal(a, ref.forward(otok, omask, atok, ptok, pmask))
+    assert not torch.equal(a, last)
+    ptok2 = ptok.clone()                                   # different storage, same values -> rebuilt, same result
+    assert torch.equal(pol.forward(otok, omask, atok, ptok2, pmask), a)
+
+
 def test_errors_mirror_reference():
     cfg = syn.config("2M")
     sd = syn.make_state_dict(cfg, 0)

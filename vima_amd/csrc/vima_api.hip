@@ -131,6 +131,12 @@ struct VimaHandle {
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<hipEvent_t> ev_layer;   // per decoder layer: "prompt K/V of layer i projected" (aux -> main)
+  // cross-step prompt K/V cache: per-layer key_value(prompt + pos-emb) (components.py:175) is
+  // loop-invariant across the env steps of an episode
+  void* kv_cache = nullptr;
+  size_t kv_cache_bytes = 0;
+  int kv_B = 0, kv_Lp = 0;
+  bool kv_valid = false;
   std::map<std::string, HostParam> host;       // staged until finalize
   std::vector<void*> owned;                     // device allocations of packed weights
   Arena arena;
@@ -804,6 +810,7 @@ void vima_destroy(VimaHandle* h) {
   h->arena.release();
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->ev_layer) (void)hipEventDestroy(e);
+  if (h->kv_cache) (void)hipFree(h->kv_cache);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -979,7 +986,7 @@ int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, cons
 
 int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
                 int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
-                float* out, vima_stream_t stream) {
+                int kv_cache_mode, float* out, vima_stream_t stream) {
   if (int e = check_ready(h)) return e;
   const int E = h->cfg.embed_dim;
   if (T <= 0 || B <= 0 || Q <= 0) return fail("vima_decode: empty input");
@@ -999,12 +1006,33 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
   void* qn = R.wsT((size_t)rq * E);
   void* Qb = R.wsT((size_t)rq * E);
   // The prompt K/V projections (components.py:175) depend only on the prompt, not on the token stream: with dual_stream
-  // they are all issued on the auxiliary stream up front (one buffer per layer) and overlap the serial decoder chain.
+  // they are all issued on the auxiliary stream up front (one buffer per layer) and overlap the serial decoder chain;
+  // with kv_cache_mode 1/2 they live in a handle-owned cache that survives across calls (one episode = one prompt).
   const int NL = h->cfg.xf_n_layers;
-  const bool dual = h->dual_stream != 0;
+  if (kv_cache_mode < 0 || kv_cache_mode > 2) return fail("vima_decode: kv_cache_mode must be 0, 1 or 2");
+  const bool use_cache = kv_cache_mode != 0;
+  const bool build_kv = kv_cache_mode != 2;
+  const size_t kv_layer_bytes = (size_t)rp * 2 * E * h->esz();
+  if (kv_cache_mode == 2 && !(h->kv_valid && h->kv_B == B && h->kv_Lp == Lp))
+    return fail("vima_decode: kv_cache_mode 2 without a matching cache (build it with mode 1 for the same B, Lp)");
+  if (kv_cache_mode == 1) {
+    h->kv_valid = false;
+    if (h->kv_cache_bytes < kv_layer_bytes * NL) {
+      HIPCK(hipDeviceSynchronize());
+      if (h->kv_cache) (void)hipFree(h->kv_cache);
+      h->kv_cache = nullptr; h->kv_cache_bytes = 0;
+      HIPCK(hipMalloc(&h->kv_cache, kv_layer_bytes * NL));
+      h->kv_cache_bytes = kv_layer_bytes * NL;
+    }
+  }
+  const bool dual = h->dual_stream != 0 && build_kv;
   std::vector<void*> KVs(NL);
-  for (int i = 0; i < (dual ? NL : 1); ++i) KVs[i] = R.wsT((size_t)rp * 2 * E);
-  if (!dual) for (int i = 1; i < NL; ++i) KVs[i] = KVs[0];
+  if (use_cache) {
+    for (int i = 0; i < NL; ++i) KVs[i] = reinterpret_cast<char*>(h->kv_cache) + kv_layer_bytes * i;
+  } else {
+    for (int i = 0; i < (dual ? NL : 1); ++i) KVs[i] = R.wsT((size_t)rp * 2 * E);
+    if (!dual) for (int i = 1; i < NL; ++i) KVs[i] = KVs[0];
+  }
   void* ctx = R.wsT((size_t)rq * E);
   float* a32 = R.ws<float>((size_t)rq * E);
   void* aT = R.wsT((size_t)rq * E);
@@ -1016,8 +1044,9 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
   if (R.err) return R.err;
   OTHER(R, launch_dec_embed(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, dmask, T, B, Q, L_act, E,
                             h->bf16, R.st), "dec_embed");
-  OTHER(R, launch_prompt_pos(prompt, stride_b, stride_l, prompt_mask, h->xpos_emb, h->cfg.xattn_n_positions, pT, B, Lp, E,
-                             h->bf16, R.st), "prompt_pos");
+  if (build_kv)
+    OTHER(R, launch_prompt_pos(prompt, stride_b, stride_l, prompt_mask, h->xpos_emb, h->cfg.xattn_n_positions, pT, B, Lp, E,
+                               h->bf16, R.st), "prompt_pos");
   if (dual) {
     while ((int)h->ev_layer.size() < NL) {
       hipEvent_t e;
@@ -1039,7 +1068,8 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
     R.ln(x32, E, D.xln_g, D.xln_b, 1e-5f, 0, rq, E, nullptr, qn);
     R.linear(qn, E, D.q, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, Qb, E);
     if (dual) HIPCK(hipStreamWaitEvent(R.st, h->ev_layer[i], 0));
-    else R.linear(pT, E, D.kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+    else if (build_kv)   // single stream: project right before use (without a cache all layers share one buffer)
+      R.linear(pT, E, D.kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
     AttnArgs a;
     a.q = Qb; a.ldq = E; a.k = KV; a.ldk = 2 * E; a.v = R.offT(KV, E); a.ldv = 2 * E; a.out = ctx; a.ldo = E;
     a.kmask = prompt_mask; a.B = B; a.H = Hx; a.Lq = Lq; a.Lk = Lp; a.D = E / Hx;
@@ -1067,6 +1097,7 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
   }
   OTHER(R, launch_gather_pred(x32, out, T, B, Q, Lq, E, R.st), "gather_pred");
   if (dual && join_aux(R)) return 1;
+  if (kv_cache_mode == 1 && !R.err) { h->kv_valid = true; h->kv_B = B; h->kv_Lp = Lp; }
   return R.err;
 }
 
