@@ -20,7 +20,10 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL (must be set before the runtime starts)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -131,6 +134,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--steps-history", type=int, default=1, help="T: observation steps in the history (T-1 past actions)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (vima_set_option), repeatable")
     args = ap.parse_args()
 
@@ -162,12 +166,15 @@ def main():
         pol.set_option(k, int(v))
     B = args.batch
     prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=args.words, q_per_view=args.qv, seed=1236 + rank), dev)
-    obs = syn.to_device(syn.make_obs(1, B, args.qv, seed=1336 + rank), dev)
+    T = args.steps_history
+    obs = syn.to_device(syn.make_obs(T, B, args.qv, seed=1336 + rank), dev)
+    past = syn.to_device(syn.make_actions(T - 1, B, seed=1436 + rank), dev) if T > 1 else None
 
     def step():
         ptok, pmask = pol.forward_prompt_assembly(prompts)
         otok, omask = pol.forward_obs_token(obs)
-        pred = pol.forward(otok, omask, None, ptok, pmask)
+        atok = pol.forward_action_token(past) if past is not None else None
+        pred = pol.forward(otok, omask, atok, ptok, pmask)
         logits = pol.action_logits(pred[-1])
         return parallel.all_gather_logits(logits, global_batch=B * world) if world > 1 else logits
 
@@ -197,7 +204,8 @@ def main():
 
     def warm_step():
         otok, omask = pol.forward_obs_token(obs)
-        pred = pol.forward(otok, omask, None, ptok_c, pmask_c)
+        atok = pol.forward_action_token(past) if past is not None else None
+        pred = pol.forward(otok, omask, atok, ptok_c, pmask_c)
         return pol.action_logits(pred[-1])
 
     warm_step()
@@ -221,7 +229,7 @@ def main():
     prof = pol.prof_read()
     pol.prof_enable(False)
 
-    cold, warm = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, 1)
+    cold, warm = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, T)
     peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
     gemm = prof["gemm"]
     gemm_tflops = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
@@ -250,7 +258,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"VIMA-{args.model} COLD policy forward (prompt assembly ViT+T5, obs ViT, XAttnGPT, action head) "
-                                   f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [{args.words} words + 1 image]), {Q} object tokens/obs, T=1",
+                                   f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [{args.words} words + 1 image]), {Q} object tokens/obs, T={T}",
                        "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}",
                        "samples_per_s": round(world * B * args.steps / dt, 1),
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),

@@ -127,8 +127,9 @@ int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float
 int vima_t5_bucket(int relative_position);
 
 /* ---- tuning / instrumentation ---------------------------------------------------------------------------------- */
-/* key in {"attn_impl" (0 generic, 1 mfma), "gemm_variant" (0 builtin LDS-DMA, 1 asm LDS-DMA),
- *         "gemm_tile" (0 auto, 1 128x128, 2 256x256), "vit_chunk" (crops)} */
+/* key in {"attn_impl" (0 generic, 1 mfma), "attn_split", "attn4_min_lq", "gemm_variant" (0 builtin LDS-DMA, 1 asm LDS-DMA),
+ *         "gemm_tile" (0 auto, 1 128x128, 2 256x256 8 waves, 3 256x128 ring, 4 256x256 4 waves), "gemm_raster",
+ *         "gemm_epi" (1 LDS-transposed epilogue), "vit_chunk" (crops), "vit_prune_last", "dual_stream"} */
 int vima_set_option(VimaHandle* h, const char* key, int64_t value);
 /* When enabled every kernel launch is bracketed by HIP events on the launch stream and attributed to a class:
  * 0 = GEMM, 1 = attention, 2 = other. vima_prof_read synchronises and returns per class

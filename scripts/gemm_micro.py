@@ -20,8 +20,6 @@ def main():
     pol._ensure_handle()
     pol.set_option("gemm_tile", tile)
     pol.set_option("gemm_raster", int(os.environ.get("RASTER", "0")))
-    pol.set_option("gemm_spread", int(os.environ.get("SPREAD", "0")))
-    pol.set_option("gemm_prio", int(os.environ.get("PRIO", "0")))
     pol.set_option("gemm_epi", int(os.environ.get("EPI", "1")))
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * 0.03
@@ -48,7 +46,7 @@ def main():
         print(f"  stamps over {d.shape[0]} workgroups (shader clocks): prologue {t[:, 1].mean():.0f}  main loop {(t[:, 2] - t[:, 1]).mean():.0f}  "
               f"epilogue {(t[:, 3] - t[:, 2]).mean():.0f}  total {t[:, 3].mean():.0f}; kernel span {(d[:, 3].max() - d[:, 0].min()):.0f}")
     ms = pr["ms"] / max(pr["launches"], 1)
-    print(f"M{M} N{N} K{K} tile{tile} raster{os.environ.get('RASTER', '0')} epi{os.environ.get('EPI', '1')} spread{os.environ.get('SPREAD', '0')} prio{os.environ.get('PRIO', '0')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    print(f"M{M} N{N} K{K} tile{tile} raster{os.environ.get('RASTER', '0')} epi{os.environ.get('EPI', '1')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

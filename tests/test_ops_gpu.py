@@ -45,7 +45,7 @@ def test_linear_epilogues(prec, variant, M, N, K):
         assert max_rel(out, ref) < (2e-3 if prec == "bf16" else 2e-5), (act, use_b, use_m, use_r)
 
 
-@pytest.mark.parametrize("tile", [2, 3])
+@pytest.mark.parametrize("tile", [2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(520, 768, 768), (256, 256, 64), (1000, 1300, 3072), (77, 520, 1536), (300, 200, 128)])
 def test_linear_large_tile(M, N, K, tile):
     """The 256x256 / 8-wave (tile 2) and 256x128 / 3-stage-ring (tile 3) paths (bf16), forced on shapes with ragged

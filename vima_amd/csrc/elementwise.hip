@@ -290,19 +290,41 @@ __global__ __launch_bounds__(256) void prompt_pos_kernel(const float* __restrict
                                                           const float* __restrict__ pos_table, int n_pos, T* out, int B,
                                                           int Lp, int E) {
   extern __shared__ int pos_dyn[];
+  __shared__ int part[256];
   const int b = blockIdx.x;
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int l = 0; l < Lp; ++l) {
+  // cumsum(mask) - 1 over the Lp positions of sample b: each thread owns a contiguous run, block-wide exclusive scan of
+  // the run totals (Hillis-Steele in LDS), then the local prefix -- no serial chain of dependent global loads
+  const int per = (Lp + 255) / 256;
+  const int l0 = threadIdx.x * per;
+  int cnt = 0;
+  for (int j = 0; j < per; ++j) {
+    const int l = l0 + j;
+    if (l < Lp) cnt += mask[(long long)b * Lp + l] ? 1 : 0;
+  }
+  part[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - cnt;   // exclusive prefix of this thread's run
+  for (int j = 0; j < per; ++j) {
+    const int l = l0 + j;
+    if (l < Lp) {
       run += mask[(long long)b * Lp + l] ? 1 : 0;
-      int p = run - 1;
-      p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
-      pos_dyn[l] = p;
+      int pp = run - 1;
+      pp = pp < 0 ? 0 : (pp >= n_pos ? n_pos - 1 : pp);
+      pos_dyn[l] = pp;
     }
   }
   __syncthreads();
+  // blockIdx.y selects a slab of 64 positions to copy (the cheap scan above is redone per slab for parallelism)
   const int e4 = E >> 2;
-  for (int i = threadIdx.x; i < Lp * e4; i += 256) {
+  const int lbeg = blockIdx.y * 64;
+  const int lend = lbeg + 64 < Lp ? lbeg + 64 : Lp;
+  for (int i = threadIdx.x + lbeg * e4; i < lend * e4; i += 256) {
     const int l = i / e4, c = (i % e4) * 4;
     const float4 a = *reinterpret_cast<const float4*>(prompt + b * sb + l * sl + c);
     const float4 p = *reinterpret_cast<const float4*>(pos_table + (long long)pos_dyn[l] * E + c);
@@ -424,10 +446,10 @@ int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uin
   if (E % 4 || sb % 4 || sl % 4) return (int)hipErrorInvalidValue;
   const size_t sh = (size_t)Lp * sizeof(int);
   if (is_bf16)
-    hipLaunchKernelGGL(prompt_pos_kernel<bf16_t>, dim3(B), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
+    hipLaunchKernelGGL(prompt_pos_kernel<bf16_t>, dim3(B, (Lp + 63) / 64), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
                        (bf16_t*)outT, B, Lp, E);
   else
-    hipLaunchKernelGGL(prompt_pos_kernel<float>, dim3(B), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
+    hipLaunchKernelGGL(prompt_pos_kernel<float>, dim3(B, (Lp + 63) / 64), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
                        (float*)outT, B, Lp, E);
   return (int)hipGetLastError();
 }

@@ -39,8 +39,9 @@ namespace {
 constexpr bool kDephase = VIMA_GEMM_DEPHASE != 0;   // waves sharing a SIMD prefetch fragments at different points of a step
 constexpr bool kInterleaveDma = VIMA_GEMM_INTERLEAVE_DMA != 0;   // DMA pieces issued between the MFMAs of the last k-step
 
-template <int BM_, int BN_, int WM_, int WN_, int RB_, int NS_>
+template <int BM_, int BN_, int WM_, int WN_, int RB_, int NS_, int MINW_ = 2>
 struct Tile {
+  static constexpr int MINW = MINW_;             // __launch_bounds__ waves per SIMD (1 -> the wave may use all 512 registers)
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int RB = RB_;                 // bytes of K per tile row (one K-slice): 128 or 64
   static constexpr int NS = NS_;                 // LDS stages
@@ -62,6 +63,7 @@ struct Tile {
 using TileS = Tile<128, 128, 2, 2, 128, 2>;   // 64 KiB, 2 workgroups / CU
 using TileL = Tile<256, 256, 2, 4, 128, 2>;   // 128 KiB, 1 workgroup / CU, 8 waves
 using TileM = Tile<256, 128, 2, 2, 64, 3>;    // 72 KiB, 2 workgroups / CU, 4 waves of 128x64, 3-deep ring of 32-wide slices
+using TileX = Tile<256, 256, 2, 2, 128, 2, 1>; // 128 KiB, 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers)
 
 template <int RB> __device__ __forceinline__ int swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
@@ -143,15 +145,13 @@ struct GemmDev {
   int mtiles, ntiles;
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
   int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
-  int spread;   // LDS-DMA issue: 0 = whole next slice at the top of the current one, 1 = spread over the k-steps
-  int prio;     // s_setprio(1) around the MFMA clusters
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
   long long* dbg;   // optional: 4 shader-clock stamps per workgroup (start, main loop start, main loop end, end)
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
 template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS>
-__global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
+__global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TL::RB, NS = TL::NS, CPR = TL::CPR;
   constexpr int BK = RB / (int)sizeof(T);
@@ -367,12 +367,14 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
       // 32-row x 64-column slabs through a private 16 KiB LDS region (free after the main loop) and finishes the
       // epilogue row-contiguously: 16 lanes cover one 64-column row segment, so every global access (gate `mul`,
       // residual, fp32 / bf16 stores) is a full 128/256-byte line.
-      static_assert(NI == 2, "LDS epilogue assumes a 64-column wave tile");
-      constexpr int LDE = NI * 32 + 4;                      // padded fp32 row stride: conflict-free ds_write_b128
+      constexpr int WCOLS = NI * 32;                        // columns of the wave tile
+      constexpr int LDE = WCOLS + 4;                        // padded fp32 row stride: conflict-free ds_write_b128
+      constexpr int LPR = WCOLS / 4;                        // lanes per row in the read-back phase
+      constexpr int RPI = 64 / LPR;                         // rows per wave-instruction
       static_assert(TL::SMEM_BYTES / NW >= 32 * LDE * 4, "per-wave LDS slab for the epilogue");
       float* stage = reinterpret_cast<float*>(smem + w * (TL::SMEM_BYTES / NW));
-      const int rr = lane >> 4, cc = (lane & 15) * 4;
-      const int n = n0 + wn * (NI * 32) + cc;
+      const int rr = lane / LPR, cc = (lane % LPR) * 4;
+      const int n = n0 + wn * WCOLS + cc;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -381,14 +383,14 @@ __global__ __launch_bounds__(TL::THREADS, 2) void gemm_kernel(const GemmDev p) {
           for (int q = 0; q < 4; ++q) {
             const int nl = ni * 32 + 8 * q + 4 * hi;
             float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
-            const int nb = n0 + wn * (NI * 32) + nl;
+            const int nb = n0 + wn * WCOLS + nl;
             if (bias && nb < p.N) { const float4 b = load4(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
             *reinterpret_cast<float4*>(stage + l31 * LDE + nl) = v;
           }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int r = it * 4 + rr;
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int r = it * RPI + rr;
           float4 v = *reinterpret_cast<const float4*>(stage + r * LDE + cc);
           const int m = m0 + wm * (MI * 32) + mi * 32 + r;
           if (m < p.M && n < p.N) {
@@ -463,7 +465,7 @@ inline int gemm_variant() {
   if (g_gemm_variant < 0) g_gemm_variant = env_int("VIMA_GEMM_VARIANT", 1) ? 1 : 0;
   return g_gemm_variant;
 }
-int g_gemm_spread = -1, g_gemm_prio = -1, g_gemm_epi = -1;
+int g_gemm_epi = -1;
 long long* g_gemm_dbg = nullptr;
 inline int env_cached(const char* name, int& cache, int dflt) {
   if (cache < 0) cache = env_int(name, dflt);
@@ -499,8 +501,6 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.ntiles = (a.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
   d.raster = gemm_raster();
-  d.spread = env_cached("VIMA_GEMM_SPREAD", g_gemm_spread, 1);
-  d.prio = env_cached("VIMA_GEMM_PRIO", g_gemm_prio, 0);
   d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1);
   d.dbg = g_gemm_dbg;
   {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
@@ -555,8 +555,9 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 224) && waste < 1.15;
     if (gemm_tile() == 1) large = false;
-    if (gemm_tile() == 2 || gemm_tile() == 3) large = v;
+    if (gemm_tile() >= 2) large = v;
     if (large && gemm_tile() == 3) return launch_tile<T, TileM, true>(d, a, v, st);
+    if (large && gemm_tile() == 4) return launch_tile<T, TileX, true>(d, a, v, st);
     if (large) return launch_tile<T, TileL, true>(d, a, v, st);
   }
   if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);
@@ -571,8 +572,6 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st) {
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_tile(int v) { g_gemm_tile = v; }
 void set_gemm_raster(int v) { g_gemm_raster = v; }
-void set_gemm_spread(int v) { g_gemm_spread = v; }
-void set_gemm_prio(int v) { g_gemm_prio = v; }
 void set_gemm_epi(int v) { g_gemm_epi = v; }
 void set_gemm_dbg(long long* p) { g_gemm_dbg = p; }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }

@@ -873,8 +873,6 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_variant") set_gemm_variant((int)value);
   else if (k == "gemm_tile") set_gemm_tile((int)value);
   else if (k == "gemm_raster") set_gemm_raster((int)value);
-  else if (k == "gemm_spread") set_gemm_spread((int)value);
-  else if (k == "gemm_prio") set_gemm_prio((int)value);
   else if (k == "gemm_epi") set_gemm_epi((int)value);
   else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
