@@ -45,6 +45,43 @@ def test_linear_epilogues(prec, variant, M, N, K):
         assert max_rel(out, ref) < (2e-3 if prec == "bf16" else 2e-5), (act, use_b, use_m, use_r)
 
 
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (1000, 1304, 1536), (77, 520, 128)])
+def test_linear_bf16_output_path(M, N, K, tile):
+    """GEMM epilogues that write ONLY the bf16 operand copy (QKV, MLP hidden, K/V projections): 16-byte-store path of the
+    LDS-transposed epilogue, with bias / activation / gate multiply / residual."""
+    pol = bare_policy("bf16")
+    pol.set_option("gemm_tile", tile)
+    pol.set_option("op_bf16_out", 1)
+    try:
+        g = torch.Generator().manual_seed(M + N + K + tile)
+        for act, use_b, use_m, use_r in [(0, 0, 0, 0), (3, 1, 0, 0), (2, 1, 1, 0), (0, 1, 0, 1)]:
+            A = torch.randn(M, K, generator=g)
+            W = torch.randn(N, K, generator=g) * K ** -0.5
+            b = torch.randn(N, generator=g) if use_b else None
+            m = torch.randn(M, N, generator=g) if use_m else None
+            r = torch.randn(M, N, generator=g) if use_r else None
+            ref = bf(A) @ bf(W).T
+            if b is not None:
+                ref = ref + b
+            ref = ACTS[act](ref)
+            if m is not None:
+                ref = ref * bf(m)
+            if r is not None:
+                ref = ref + r
+            ref = bf(ref)
+            d = [None if t is None else t.cuda() for t in (A, W, b, m, r)]
+            out = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, act,
+                                               ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            assert max_rel(out, ref) < 6e-3, (act, use_b, use_m, use_r)   # one extra bf16 rounding of the output
+    finally:
+        pol.set_option("gemm_tile", 0)
+        pol.set_option("op_bf16_out", 0)
+
+
 @pytest.mark.parametrize("tile", [2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(520, 768, 768), (256, 256, 64), (1000, 1300, 3072), (77, 520, 1536), (300, 200, 128)])
 def test_linear_large_tile(M, N, K, tile):

@@ -146,6 +146,7 @@ struct GemmDev {
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
   int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
+  int wide8;    // bf16-only output with 8-column alignment: 16-byte stores in the LDS epilogue
   long long* dbg;   // optional: 4 shader-clock stamps per workgroup (start, main loop start, main loop end, end)
 };
 
@@ -388,6 +389,36 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
             *reinterpret_cast<float4*>(stage + l31 * LDE + nl) = v;
           }
+        if constexpr (sizeof(T) == 2) {
+          if (p.wide8) {   // bf16-only output: 8 columns per lane -> 16-byte stores, half the store instructions
+            constexpr int LPR8 = WCOLS / 8, RPI8 = 64 / LPR8;
+            const int rr8 = lane / LPR8, cc8 = (lane % LPR8) * 8;
+            const int n8 = n0 + wn * WCOLS + cc8;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI8; ++it) {
+              const int r = it * RPI8 + rr8;
+              float4 v0 = *reinterpret_cast<const float4*>(stage + r * LDE + cc8);
+              float4 v1 = *reinterpret_cast<const float4*>(stage + r * LDE + cc8 + 4);
+              const int m = m0 + wm * (MI * 32) + mi * 32 + r;
+              if (m < p.M && n8 < p.N) {
+                long long orow = m;
+                if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
+                if (mul) {
+                  const float4 g0 = load4(mul + (long long)m * p.ldmul + n8), g1 = load4(mul + (long long)m * p.ldmul + n8 + 4);
+                  v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w; v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
+                }
+                if (res) {
+                  const float4 r0 = load4(res + (long long)m * p.ldres + n8), r1 = load4(res + (long long)m * p.ldres + n8 + 4);
+                  v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
+                }
+                uint4 o;
+                o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
+                *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
+              }
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
           const int r = it * RPI + rr;
@@ -549,6 +580,11 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.res) v = v && aligned_to(a.res, 16) && (a.ldres % 4 == 0) && (a.bsRes % 4 == 0);
   if (a.out32) v = v && aligned_to(a.out32, 16) && (a.ld32 % 4 == 0) && (a.bs32 % 4 == 0);
   if (a.outT) v = v && aligned_to(a.outT, 4 * es) && (a.ldT % 4 == 0) && (a.bsT % 4 == 0);
+  d.wide8 = 0;
+  if constexpr (sizeof(T) == 2) {
+    d.wide8 = (v && a.outT && !a.out32 && a.N % 8 == 0 && a.ldT % 8 == 0 && a.bsT % 8 == 0 && aligned_to(a.outT, 16) &&
+               (!a.mul || (a.ldmul % 8 == 0 && a.bsMul % 8 == 0 && aligned_to(a.mul, 16)))) ? 1 : 0;
+  }
   if constexpr (sizeof(T) == 2) {
     // TileL when the 256x256 grid still fills the chip (>= ~1 workgroup per CU) and padding waste is small
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;

@@ -126,6 +126,7 @@ struct VimaHandle {
   int attn_impl = 1;
   int vit_chunk = 16384;
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
+  int op_bf16_out = 0;      // vima_op_linear: route the result through the operand-type output (tests the T store paths)
   int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
                             // GEMM epilogues) of one half overlap the MFMA-bound GEMM main loops of the other half
   hipStream_t aux = nullptr;
@@ -880,6 +881,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else if (k == "dual_stream") h->dual_stream = (int)value;
+  else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
 }
@@ -1147,6 +1149,11 @@ int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int Rn, float*
 }
 
 // ---------------------------------------------------------------------------------------------- operator-level
+__global__ void widen_kernel(const bf16_t* in, float* out, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = bf16_to_f32(in[i]);
+}
+
 int vima_op_linear(VimaHandle* h, const float* A, const float* W, const float* bias, const float* mul, const float* res, int M,
                    int N, int K, int act, float* out, vima_stream_t stream) {
   if (!h) return fail("null handle");
@@ -1163,7 +1170,17 @@ int vima_op_linear(VimaHandle* h, const float* A, const float* W, const float* b
   if (mul) OTHER(R, launch_cast(mul, mT, (long long)M * N, h->bf16, R.st), "cast");
   GemmArgs a;
   a.A = aT; a.lda = K; a.W = wT; a.ldw = K; a.M = M; a.N = N; a.K = K; a.bias = bias; a.act = act; a.mul = mT; a.ldmul = N;
-  a.res = res; a.ldres = N; a.out32 = out; a.ld32 = N;
+  a.res = res; a.ldres = N;
+  if (h->op_bf16_out && h->bf16) {   // exercise the operand-type (bf16) output path, then widen
+    void* oT = R.wsT((size_t)M * N);
+    if (R.err) return R.err;
+    a.outT = oT; a.ldT = N;
+    if (R.gemm(a)) return R.err;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, R.st, (const bf16_t*)oT, out,
+                       (long long)M * N);
+    return R.other((int)hipGetLastError(), "widen");
+  }
+  a.out32 = out; a.ld32 = N;
   return R.gemm(a);
 }
 
@@ -1173,11 +1190,6 @@ int vima_op_layernorm(VimaHandle* h, const float* x, const float* gamma, const f
   HIPCK(hipSetDevice(h->device));
   Run R{h, (hipStream_t)stream};
   return R.ln(x, E, gamma, beta, eps, rms, rows, E, out, nullptr);
-}
-
-__global__ void widen_kernel(const bf16_t* in, float* out, long long n) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = bf16_to_f32(in[i]);
 }
 
 int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float* v, const uint8_t* kmask, const float* relbias,
