@@ -82,7 +82,7 @@ def test_linear_bf16_output_path(M, N, K, tile):
         pol.set_option("op_bf16_out", 0)
 
 
-@pytest.mark.parametrize("tile", [2, 3, 4])
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(520, 768, 768), (256, 256, 64), (1000, 1300, 3072), (77, 520, 1536), (300, 200, 128)])
 def test_linear_large_tile(M, N, K, tile):
     """The 256x256 / 8-wave (tile 2) and 256x128 / 3-stage-ring (tile 3) paths (bf16), forced on shapes with ragged

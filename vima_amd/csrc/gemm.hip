@@ -36,6 +36,11 @@ namespace {
 #ifndef VIMA_GEMM_DEPHASE
 #define VIMA_GEMM_DEPHASE 1
 #endif
+#ifndef VIMA_GEMM_ABLATE
+#define VIMA_GEMM_ABLATE 0
+#endif
+// experiment only (wrong results): 1 = no LDS-DMA in the main loop, 2 = no s_barrier, 4 = no fragment ds_reads, 8 = no vmcnt wait, 16 = no MFMAs
+constexpr int kAblate = VIMA_GEMM_ABLATE;
 constexpr bool kDephase = VIMA_GEMM_DEPHASE != 0;   // waves sharing a SIMD prefetch fragments at different points of a step
 constexpr bool kInterleaveDma = VIMA_GEMM_INTERLEAVE_DMA != 0;   // DMA pieces issued between the MFMAs of the last k-step
 
@@ -64,6 +69,8 @@ using TileS = Tile<128, 128, 2, 2, 128, 2>;   // 64 KiB, 2 workgroups / CU
 using TileL = Tile<256, 256, 2, 4, 128, 2>;   // 128 KiB, 1 workgroup / CU, 8 waves
 using TileM = Tile<256, 128, 2, 2, 64, 3>;    // 72 KiB, 2 workgroups / CU, 4 waves of 128x64, 3-deep ring of 32-wide slices
 using TileX = Tile<256, 256, 2, 2, 128, 2, 1>; // 128 KiB, 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers)
+using TileH4 = Tile<256, 256, 2, 4, 64, 4>;   // 128 KiB, 8 waves, ring of FOUR 32-wide K-slices (DMA lead 3 half-slices)
+using TileH5 = Tile<256, 256, 2, 4, 64, 5>;   // 160 KiB, ring of FIVE 32-wide K-slices (DMA lead 4 half-slices = 2x TileL)
 
 template <int RB> __device__ __forceinline__ int swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
@@ -80,10 +87,27 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // ds_read of every K-slice (it cannot prove the DMA target stage and the stage being read are disjoint), which
 // serialises load and MFMA inside a wave. M0 carries the wave-uniform LDS byte address and is written in the same
 // statement that uses it (hipcc reserves M0 and does not preserve it across statements).
+#ifndef VIMA_GEMM_M0MODE
+#define VIMA_GEMM_M0MODE 0
+#endif
 __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_addr) {
+#if VIMA_GEMM_M0MODE == 0
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+#elif VIMA_GEMM_M0MODE == 1   // experiment: M0 declared clobbered, never restored
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(gsrc), "s"(lds_byte_addr) : "memory", "m0");
+#else                         // experiment (wrong results): M0 not written at all
+  asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_byte_addr) : "memory");
+#endif
+}
+
+// SADDR form: uniform 64-bit base in SGPRs + per-lane unsigned 32-bit BYTE offset (half the address registers and VALU)
+__device__ __forceinline__ void glds16_asm_s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
 // wait for this wave's outstanding LDS-DMA + LDS reads, then workgroup barrier (compiler memory barrier too)
@@ -143,11 +167,12 @@ struct GemmDev {
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
   int mtiles, ntiles;
+  int vtotal;   // persistent kernel: number of virtual tile ids = ceil8(mtiles) * ntiles
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
   int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
   int wide8;    // bf16-only output with 8-column alignment: 16-byte stores in the LDS epilogue
-  long long* dbg;   // optional: 4 shader-clock stamps per workgroup (start, main loop start, main loop end, end)
+  long long* dbg;   // optional: 8 debug slots per workgroup (shader-clock stamps of the 4 phases, real time, placement)
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
@@ -196,8 +221,18 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 
   const T* A = reinterpret_cast<const T*>(p.A) + (long long)z * p.bsA;
   const T* W = reinterpret_cast<const T*>(p.W) + (long long)z * p.bsW;
+  // 8 slots per workgroup: 0-3 shader-clock stamps, 4/5 constant-rate (100 MHz) real-time at start/end, 6 HW_ID, 7 XCC_ID
   auto stamp = [&](int slot) {
-    if (p.dbg && tid == 0) p.dbg[(long long)blockIdx.x * 4 + slot] = (long long)__builtin_readcyclecounter();
+    if (p.dbg && tid == 0) {
+      long long* d = p.dbg + (long long)blockIdx.x * 8;
+      d[slot] = (long long)__builtin_readcyclecounter();
+      if (slot == 0) {
+        d[4] = (long long)__builtin_amdgcn_s_memrealtime();
+        d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        d[7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+      }
+      if (slot == 3) d[5] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
   };
   stamp(0);
 
@@ -255,17 +290,21 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   // operands are already in registers). VMEM loads retire in order, so `vmcnt(n * NP)` = "all but the n youngest slices".
   auto wait_slices_and_barrier = [&](int younger) {   // `younger` slices of DMA may stay in flight (wave-uniform)
     if constexpr (ASMLDS) {
-      if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (kAblate & 8) younger = 100;
+      if (younger >= 100) {}
+      else if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NP) : "memory");
+      else if (younger == 2 || NS <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NP) : "memory");
+      else if (younger == 3 || NS <= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS > 3 ? 3 * NP : 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS > 4 ? 4 * NP : 0) : "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) via the builtin: keeps hipcc's scoreboard exact
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(kAblate & 2)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     } else {
       wait_all_and_barrier();
     }
   };
-  static_assert(NS == 2 || NS == 3, "ring depth");
+  static_assert(NS >= 2 && NS <= 5 && (NS - 1) * NP <= 63, "ring depth (vmcnt is a 6-bit counter)");
   const int npro = nk < NS ? nk : NS;
   for (int t = 0; t < npro; ++t) {
 #pragma unroll
@@ -278,11 +317,34 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   for (int mi = 0; mi < MI; ++mi) fa[0][mi].template load<RB>(smem, arow + mi * 32, 0, hi);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) fw[0][ni].template load<RB>(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
+  if constexpr (kAblate & 4) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fa[1][mi] = fa[0][mi];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fw[1][ni] = fw[0][ni];
+  }
   // The two waves that share a SIMD (w and w + NW/2 of an 8-wave workgroup) run the SAME instruction stream in lock
   // step after every barrier; if both fetch fragments at the same moment the matrix pipe idles, then both compete
   // for it. The second half of the waves therefore issues its fragment prefetch in the MIDDLE of each step's MFMAs.
   auto main_loop = [&](auto late_tag) {
     constexpr bool LATE = decltype(late_tag)::value;
+    constexpr int PPM = (NP + MI * NI - 1) / (MI * NI);
+    // MFMAs of k-step buffer cb for mi in [mi0, mi1); when `dma`, the pieces of `slice` are issued into `stage` one
+    // (PPM) per MFMA, in MFMA order
+    auto mma_block = [&](int mi0, int mi1, int cb, bool dma, int stage, int slice) {
+#pragma unroll
+      for (int mi = mi0; mi < mi1; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (!(kAblate & 16)) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+          if (dma) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = (mi * NI + ni) * PPM; j < (mi * NI + ni + 1) * PPM && j < NP; ++j) issue_piece(stage, slice, j);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    };
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int nxt = cur + 1 == NS ? 0 : cur + 1;
@@ -296,29 +358,25 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
         if (kk + 1 < KSTEPS) {   // prefetch the next step's fragments while this step's MFMAs run
           if constexpr (LATE) {
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mi = 0; mi < MI / 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+            mma_block(0, MI / 2, cb, false, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
+          if constexpr (!(kAblate & 4)) {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
+            for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
+            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
+          }
           // pin the order: [ds_reads] then [MFMAs]; without this hipcc re-serialises read -> wait -> 2 MFMAs
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int mi = (LATE ? MI / 2 : 0); mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+          mma_block(LATE ? MI / 2 : 0, MI, cb, false, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         } else {
           // slices issued so far: up to min(nk-1, kt+NS-1); younger than kt+1 may stay in flight
           int last = kt + NS - 1;
           last = last < nk - 1 ? last : nk - 1;
           wait_slices_and_barrier(last - (kt + 1));
-          if (kt + 1 < nk) {
+          if (kt + 1 < nk && !(kAblate & 4)) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(nA, arow + mi * 32, 0, hi);
 #pragma unroll
@@ -326,20 +384,9 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           }
           __builtin_amdgcn_sched_barrier(0);
           // the DMA pieces of slice kt+NS go into the stage just freed, ONE BY ONE BETWEEN the MFMAs
-          constexpr int PPM = (NP + MI * NI - 1) / (MI * NI);
-          const bool more = kt + NS < nk;
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
-              __builtin_amdgcn_sched_barrier(0);
-              if (more) {
-#pragma unroll
-                for (int j = (mi * NI + ni) * PPM; j < (mi * NI + ni + 1) * PPM && j < NP; ++j) issue_piece(cur, kt + NS, j);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
+          const bool more = kt + NS < nk && !(kAblate & 1);
+          mma_block(0, MI, cb, more, cur, kt + NS);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       cur = nxt;
@@ -484,6 +531,286 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent GEMM
+// Measured on MI355X (scripts/gpu_job_ablate.sh, profiles/r01_gemm_ablation.md): the 256x256 main loop is NOT bound by
+// the matrix pipe but by the global->LDS path -- with the MFMAs removed it runs no faster, ~19-25 B/clk/CU however
+// the 64 KiB per K-slice are fetched (LDS-DMA, or global_load + ds_write). At K = 768 a tile therefore spends 40 k
+// clocks streaming operands and another 20 k in a prologue (first slices' latency) and an epilogue (stores) during
+// which that path idles. The persistent kernel keeps ONE workgroup per CU and treats the K-slices of all its tiles as
+// one continuous LDS-DMA stream: the first two slices of tile i+1 are requested during the last two k-slices of tile
+// i and land while tile i's epilogue runs. The epilogue stages through its own 32 KiB of LDS (32x32 fp32 slabs per
+// wave, XOR-swizzled: conflict-free for ds_write_b128 and both read-back shapes), so both ring stages stay free.
+template <int ACT>
+__global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(const GemmDev p) {
+  using T = bf16_t;
+  using TL = TileL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = TL::RB, NS = TL::NS, CPR = TL::CPR;
+  constexpr int BK = RB / (int)sizeof(T), EPC = KCfg<T>::EPC, KSTEPS = BK / 16;
+  constexpr int MI = TL::MI, NI = TL::NI, NW = TL::NW, NP = TL::PA + TL::PW;
+  constexpr int EPI_OFF = NS * TL::STAGE_BYTES;     // epilogue slabs live behind the ring: NW x 4 KiB
+  static_assert(NS == 2 && RB == 128 && NI == 2 && MI == 4 && NW == 8, "written for TileL");
+  static_assert(NP == MI * NI, "one LDS-DMA piece per MFMA of the last k-step");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int G = gridDim.x;
+  const int nk = p.K / BK;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* W = reinterpret_cast<const T*>(p.W);
+
+  // virtual tile id v -> (tm, tn): workgroup b only ever takes v = b, b + G, ... (G % 8 == 0), so v & 7 is its XCD and
+  // one XCD walks the n-tiles of one A panel back to back, as in the one-tile-per-workgroup kernel
+  auto tile_at = [&](int v, int& tm, int& tn) {
+    const int idx = v >> 3;
+    const int q = idx / p.ntiles;
+    tn = idx - q * p.ntiles;
+    tm = q * 8 + (v & 7);
+  };
+  auto next_valid = [&](int v) {
+    while (v < p.vtotal) {
+      int tm, tn;
+      tile_at(v, tm, tn);
+      if (tm < p.mtiles) return v;
+      v += G;
+    }
+    return -1;
+  };
+
+  // ---- issue cursor: the (tile, K-slice) the next LDS-DMA slice belongs to; runs up to two slices ahead of the MFMAs
+  // per-lane BYTE offsets from A / W (launcher guarantees they fit 32 bits); the k-slice offset is added at issue
+  unsigned offA[TL::PA], offW[TL::PW];
+  int iv, ikt = 0;
+  const int r0 = (w * 64 + lane) / CPR;                 // row of this lane within a 64-row piece group
+  const int c0 = ((lane % CPR) ^ swz<RB>(r0)) * 16;     // swizzled 16-B chunk (the same for every piece: swz ignores r / 64)
+  auto set_ptrs = [&](int v) {
+    int tm, tn;
+    tile_at(v, tm, tn);
+#pragma unroll
+    for (int i = 0; i < TL::PA; ++i) {
+      int ra = tm * TL::BM + i * (NW * 64 / CPR) + r0; ra = ra < p.M ? ra : p.M - 1;
+      offA[i] = (unsigned)ra * (unsigned)(p.lda * (int)sizeof(T)) + c0;
+    }
+#pragma unroll
+    for (int i = 0; i < TL::PW; ++i) {
+      int rw = tn * TL::BN + i * (NW * 64 / CPR) + r0; rw = rw < p.N ? rw : p.N - 1;
+      offW[i] = (unsigned)rw * (unsigned)(p.ldw * (int)sizeof(T)) + c0;
+    }
+  };
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue_piece = [&](int stage, int j) {
+    const int i = j < TL::PA ? j : j - TL::PA;
+    const int off = stage * TL::STAGE_BYTES + (j < TL::PA ? 0 : TL::A_BYTES) + (i * NW + w) * 1024;
+    const unsigned koff = (unsigned)(ikt * RB);
+    if (j < TL::PA) glds16_asm_s(A, offA[i] + koff, smem_base + off);
+    else glds16_asm_s(W, offW[i] + koff, smem_base + off);
+  };
+  auto advance_issue = [&]() {   // after the last piece of a slice
+    if (++ikt == nk) {
+      ikt = 0;
+      iv = next_valid(iv + G);
+      if (iv >= 0) set_ptrs(iv);
+    }
+  };
+
+  int cv = next_valid(blockIdx.x);
+  if (cv < 0) return;
+  iv = cv;
+  set_ptrs(iv);
+  for (int t = 0; t < NS; ++t) {   // nk >= NS (launcher): both slices belong to the first tile
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue_piece(t, j);
+    advance_issue();
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");   // slice 0 landed, slice 1 may be in flight
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int wm = w / TL::WN, wn = w % TL::WN;
+  const int arow = wm * (MI * 32) + l31;
+  const int wrow = wn * (NI * 32) + l31;
+  const int act = ACT >= 0 ? ACT : p.act;
+  int cur = 0;
+
+  while (true) {
+    int tm, tn;
+    tile_at(cv, tm, tn);
+    const int m0 = tm * TL::BM, n0 = tn * TL::BN;
+    auto stamp = [&](int slot) {
+      if (p.dbg && tid == 0) {
+        long long* d = p.dbg + (long long)cv * 8;
+        d[slot] = (long long)__builtin_readcyclecounter();
+        if (slot == 0) {
+          d[4] = (long long)__builtin_amdgcn_s_memrealtime();
+          d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+          d[7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+        if (slot == 3) d[5] = (long long)__builtin_amdgcn_s_memrealtime();
+      }
+    };
+    stamp(0);
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    Frag<T> fa[2][MI], fw[2][NI];
+    {
+      const char* sA = smem + cur * TL::STAGE_BYTES;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[0][mi].template load<RB>(sA, arow + mi * 32, 0, hi);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fw[0][ni].template load<RB>(sA + TL::A_BYTES, wrow + ni * 32, 0, hi);
+    }
+    stamp(1);
+    auto main_loop = [&](auto late_tag) {
+      constexpr bool LATE = decltype(late_tag)::value;
+      for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = cur ^ 1;
+        const char* sA = smem + cur * TL::STAGE_BYTES;
+        const char* sW = sA + TL::A_BYTES;
+        const char* nA = smem + nxt * TL::STAGE_BYTES;
+        const char* nW = nA + TL::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+          const int cb = kk & 1, nb = cb ^ 1;
+          if (kk + 1 < KSTEPS) {
+            if constexpr (LATE) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int mi = 0; mi < MI / 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = (LATE ? MI / 2 : 0); mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            // the next slice of the stream (slice kt+1, or slice 0 of the NEXT tile) has landed; every wave is done
+            // reading stage `cur`
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) {
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(nA, arow + mi * 32, 0, hi);
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(nW, wrow + ni * 32, 0, hi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = iv >= 0;   // wave-uniform: the stream has another slice (this tile's or a later tile's)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_piece(cur, mi * NI + ni);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            if (more) advance_issue();
+          }
+        }
+        cur = nxt;
+      }
+    };
+    if (kDephase && w >= NW / 2) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    stamp(2);
+
+    // ---------------------------------------------------------------- epilogue (32x32 fp32 slabs, private LDS region)
+    // acc[mi][ni][4q+e] = C[m0 + wm*128 + mi*32 + l31][n0 + wn*64 + ni*32 + 8q + 4hi + e]
+    // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
+    auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
+    float* stg = reinterpret_cast<float*>(smem + EPI_OFF + w * 4096);
+    const T* mul = reinterpret_cast<const T*>(p.mul);
+    T* outT = reinterpret_cast<T*>(p.outT);
+    // the epilogue's per-lane address arithmetic is tile-invariant: hipcc would hoist it out of the tile loop and keep
+    // (spill) it across the main loop. An opaque copy of the lane id pins it here.
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int el31 = elane & 31, ehi = elane >> 5;
+    const int fw_ = fsw(el31);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nbase = n0 + wn * (NI * 32) + ni * 32;
+        const int mbase = m0 + wm * (MI * 32) + mi * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+          const int nb = nbase + 8 * q + 4 * ehi;
+          if (p.bias && nb < p.N) { const float4 b = load4(p.bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+          if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+          *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
+        }
+        if (p.wide8) {   // bf16-only output: 4 lanes x 16 B per row, 16 rows per instruction
+          const int c8 = elane & 3;
+          const int n8 = nbase + c8 * 8;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r = it * 16 + (elane >> 2);
+            const int f = fsw(r);
+            float4 v0 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8) ^ f) << 2));
+            float4 v1 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8 + 1) ^ f) << 2));
+            const int m = mbase + r;
+            if (m < p.M && n8 < p.N) {
+              long long orow = m;
+              if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
+              if (mul) {
+                const float4 g0 = load4(mul + (long long)m * p.ldmul + n8), g1 = load4(mul + (long long)m * p.ldmul + n8 + 4);
+                v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w; v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
+              }
+              if (p.res) {
+                const float4 r0 = load4(p.res + (long long)m * p.ldres + n8), r1 = load4(p.res + (long long)m * p.ldres + n8 + 4);
+                v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
+              }
+              uint4 o;
+              o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
+              *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
+            }
+          }
+        } else {         // 8 lanes x 16 B (fp32) per row, 8 rows per instruction
+          const int cc = elane & 7;
+          const int n = nbase + cc * 4;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (elane >> 3);
+            float4 v = *reinterpret_cast<const float4*>(stg + r * 32 + ((cc ^ fsw(r)) << 2));
+            const int m = mbase + r;
+            if (m < p.M && n < p.N) {
+              long long orow = m;
+              if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
+              if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
+              if (p.res) { const float4 r4 = load4(p.res + (long long)m * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+              if (p.out32) store4(p.out32 + orow * p.ld32 + n, v);
+              if (outT) store4(outT + orow * p.ldT + n, v);
+            }
+          }
+        }
+      }
+    }
+    stamp(3);
+    cv = next_valid(cv + G);
+    if (cv < 0) break;
+  }
+}
+
 // 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin (TileS only). Override with VIMA_GEMM_VARIANT.
 int g_gemm_variant = -1;
 int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL, 3 force TileM (bf16 only)
@@ -528,8 +855,8 @@ int launch_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
 
 template <typename T, typename TL, bool ASMLDS>
 int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
-  d.mtiles = (a.M + TL::BM - 1) / TL::BM;
-  d.ntiles = (a.N + TL::BN - 1) / TL::BN;
+  d.mtiles = (d.M + TL::BM - 1) / TL::BM;
+  d.ntiles = (d.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
   d.raster = gemm_raster();
   d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1);
@@ -552,6 +879,45 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   }
 }
 
+int g_gemm_persist = -1;   // 1 (default): large bf16 GEMMs run on the persistent kernel; VIMA_GEMM_PERSIST / option gemm_persist
+int g_num_cu = 0;
+
+template <int ACT>
+int launch_persistent_inst(const GemmDev& d, int grid, hipStream_t st) {
+  constexpr int SMEM = TileL::SMEM_BYTES + TileL::NW * 4096;   // ring + epilogue slabs = 160 KiB
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_persistent_kernel<ACT>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
+  return (int)hipGetLastError();
+}
+
+int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cu = n / 8 * 8;
+  }
+  d.mtiles = (d.M + TileL::BM - 1) / TileL::BM;
+  d.ntiles = (d.N + TileL::BN - 1) / TileL::BN;
+  d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
+  d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
+  d.dbg = g_gemm_dbg;
+  const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
+  switch (a.act) {
+    case ACT_NONE: return launch_persistent_inst<ACT_NONE>(d, grid, st);
+    case ACT_RELU: return launch_persistent_inst<ACT_RELU>(d, grid, st);
+    case ACT_GELU: return launch_persistent_inst<ACT_GELU>(d, grid, st);
+    case ACT_QUICKGELU: return launch_persistent_inst<ACT_QUICKGELU>(d, grid, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
 template <typename T>
 int launch_t(const GemmArgs& a, hipStream_t st) {
   constexpr int BK = 128 / (int)sizeof(T);   // K granularity of the widest K-slice (TileS / TileL)
@@ -564,10 +930,15 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     return (int)hipErrorInvalidValue;
   GemmDev d;
   d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
-  {   // experiment only (wrong results): all A rows alias row 0 -> the A stream always hits cache
-    static int dbg = -1;
-    if (dbg < 0) dbg = env_int("VIMA_GEMM_DEBUG_LDA0", 0);
-    if (dbg) d.lda = 0;
+  {   // experiment only (wrong results): override the row strides of A and W (0 = every row aliases row 0)
+    static int dbg = -2;
+    if (dbg == -2) dbg = env_int("VIMA_GEMM_DEBUG_LD", -1);
+    if (dbg >= 0) {   // the caller allocates M' x K, N' x K with M' K >= M ld: the kernel then runs the M x N problem
+      d.lda = dbg; d.ldw = dbg;
+      const int m = env_int("VIMA_GEMM_DEBUG_M", 0), n = env_int("VIMA_GEMM_DEBUG_N", 0);
+      if (m > 0) d.M = m;
+      if (n > 0) d.N = n;
+    }
   }
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
@@ -594,6 +965,12 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (gemm_tile() >= 2) large = v;
     if (large && gemm_tile() == 3) return launch_tile<T, TileM, true>(d, a, v, st);
     if (large && gemm_tile() == 4) return launch_tile<T, TileX, true>(d, a, v, st);
+    if (large && gemm_tile() == 5) return launch_tile<T, TileH4, true>(d, a, v, st);
+    if (large && gemm_tile() == 6) return launch_tile<T, TileH5, true>(d, a, v, st);
+    if (large && (gemm_tile() == 0 || gemm_tile() == 2) && env_cached("VIMA_GEMM_PERSIST", g_gemm_persist, 1) && a.batch <= 1 &&
+        a.K >= 2 * 64 && gemm_raster() == 0 && env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1) &&
+        (long long)a.M * a.lda * 2 < (1LL << 32) && (long long)a.N * a.ldw * 2 < (1LL << 32))
+      return launch_persistent(d, a, st);
     if (large) return launch_tile<T, TileL, true>(d, a, v, st);
   }
   if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);
@@ -609,6 +986,7 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_tile(int v) { g_gemm_tile = v; }
 void set_gemm_raster(int v) { g_gemm_raster = v; }
 void set_gemm_epi(int v) { g_gemm_epi = v; }
+void set_gemm_persist(int v) { g_gemm_persist = v; }
 void set_gemm_dbg(long long* p) { g_gemm_dbg = p; }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
 

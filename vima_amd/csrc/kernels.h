@@ -35,6 +35,7 @@ int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin
 void set_gemm_raster(int v);        // tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
 void set_gemm_epi(int v);           // 1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
+void set_gemm_persist(int v);       // 1 = large bf16 GEMMs on the persistent (one workgroup per CU) kernel (default), 0 = one tile per workgroup
 void set_gemm_dbg(long long* p);     // debug: device buffer [blocks*4] of shader-clock stamps (nullptr = off)
 void set_gemm_tile(int v);          // 0 = auto, 1 = 128x128 (TileS), 2 = 256x256 8 waves (TileL), 3 = 256x128 ring (TileM), 4 = 256x256 4 waves (TileX)
 

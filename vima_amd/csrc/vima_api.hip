@@ -875,6 +875,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_tile") set_gemm_tile((int)value);
   else if (k == "gemm_raster") set_gemm_raster((int)value);
   else if (k == "gemm_epi") set_gemm_epi((int)value);
+  else if (k == "gemm_persist") set_gemm_persist((int)value);
   else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "attn_split") set_attn_split((int)value);
