@@ -369,7 +369,23 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
 // The T5 relative-position bias (a function of key - query only) and the additive key mask live in LDS for the whole
 // workgroup, so the softmax stage makes no global-memory access. Same S^T = K.Q^T / O^T += V^T.P^T formulation and the
 // same literal mask semantics as attn_mfma_kernel above.
-constexpr int VT4_STRIDE = 68;   // bf16 elements per V^T row: 64 keys + 4 pad = 136 B
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int VT4_STRIDE = 68;   // sizing only: the V image needs < D * 68 * 2 bytes per buffer
+// V is kept ROW-major in LDS as D/16 sub-tiles of [64 keys][16 d] (32-byte rows) and the A-fragments of O^T += V^T.P^T
+// are fetched with gfx950's transposing read (ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address
+// of (row i/4, 4 columns 4(i%4)..) and lane l receives column l of those 4 rows). One 16-byte ds_write_b128 per
+// loaded chunk replaces the eight 2-byte scatter stores of a software transpose (which were 60 % of this kernel's LDS
+// cycles, 4-way bank-conflicted). Sub-tiles 2s and 2s+1 (read together by lanes 0-15 / 16-31) are 128 B apart modulo
+// the 256-B bank row -> conflict-free reads; the writes are 2-way conflicted at most.
+template <int KEYS = 64>
+__device__ __forceinline__ constexpr int vsub_off(int s) {
+  return (s >> 1) * (2 * (KEYS * 32 + 128) + 64) + (s & 1) * (KEYS * 32 + 128);
+}
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short short4_t;
+__device__ __forceinline__ uint2 lds_read_tr16(const char* lds_ptr) {
+  const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(lds_ptr));
+  return __builtin_bit_cast(uint2, v);
+}
 
 template <int D>
 __device__ __forceinline__ int kswz(int r, int c) {
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
   constexpr int VT_BYTES = D * VT4_STRIDE * 2;
   constexpr int CH = 64 * CPR / 256;                          // chunks per thread per tile (2 for D=64, 1 for D=32)
   char* ks_base = smem4;                                       // [2][64][ROWB]
-  bf16_t* vt_base = reinterpret_cast<bf16_t*>(smem4 + 2 * KS_BYTES);   // [2][D][VT4_STRIDE]
+  char* vt_base = smem4 + 2 * KS_BYTES;                               // [2] x V image (sub-tiled, see vsub_off)
   float* madd = reinterpret_cast<float*>(smem4 + 2 * KS_BYTES + 2 * VT_BYTES);   // [nt*64]
   const int nt = (p.Lk + 63) / 64;
 
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
     const float* rb = p.relbias + (long long)h * (2 * p.Lk - 1);
     for (int j = tid; j < qpad + kpad - 1; j += 256) {
       const int delta = j - boff;                              // key - query
-      btab[j] = (delta > -p.Lk && delta < p.Lk) ? rb[delta + p.Lk - 1] : 0.0f;
+      btab[j] = (delta > -p.Lk && delta < p.Lk) ? rb[delta + p.Lk - 1] * kLog2e : 0.0f;   // log2 domain, see below
     }
   }
   __syncthreads();
@@ -447,33 +463,39 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
     for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  uint4 kreg[CH], vreg[CH];
+  // per-lane byte offset of the transposing V reads: 16-lane group g = lane>>4 reads sub-tile (g&1) [d 16(g&1)..+15],
+  // keys 4 hi + i/4 (i = lane&15; hi = g>>1), 8-byte column quad i%4. The k-slots of the P^T operand are the S^T
+  // accumulator registers: lane-half hi holds keys 4hi+{0..3} and 8+4hi+{0..3} of each 16-key step.
+  const int vlane = vsub_off((lane >> 4) & 1) + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  // staging registers of the next tile (named scalars, not arrays: hipcc kept `uint4 kreg[CH]` in scratch memory, which
+  // forced a vmcnt(0) + scratch round trip right behind every global load and exposed its full latency every tile)
+  uint4 kreg0, kreg1, vreg0, vreg1;
+  auto gaddr = [&](int t, int i, const bf16_t* base, int ld) {
+    const int id = tid + i * 256;
+    const int key = id / CPR, c = id % CPR;
+    int row = t * 64 + key;
+    row = row < p.Lk ? row : p.Lk - 1;
+    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lk + row) * ld + h * D + c * 8);
+  };
   auto gload = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int id = tid + i * 256;
-      const int key = id / CPR, c = id % CPR;
-      int row = t * 64 + key;
-      row = row < p.Lk ? row : p.Lk - 1;
-      kreg[i] = *reinterpret_cast<const uint4*>(K + ((long long)b * p.Lk + row) * p.ldk + h * D + c * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lk + row) * p.ldv + h * D + c * 8);
+    kreg0 = *gaddr(t, 0, K, p.ldk);
+    vreg0 = *gaddr(t, 0, V, p.ldv);
+    if constexpr (CH > 1) {
+      kreg1 = *gaddr(t, 1, K, p.ldk);
+      vreg1 = *gaddr(t, 1, V, p.ldv);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore1 = [&](int buf, int i, const uint4& kr, const uint4& vr) {
     char* ks = ks_base + buf * KS_BYTES;
-    bf16_t* vt = vt_base + buf * (D * VT4_STRIDE);
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int id = tid + i * 256;
-      const int key = id / CPR, c = id % CPR;
-      *reinterpret_cast<uint4*>(ks + key * ROWB + (kswz<D>(key, c) << 4)) = kreg[i];
-      const uint32_t wds[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vt[(c * 8 + 2 * e) * VT4_STRIDE + key] = (bf16_t)(wds[e] & 0xffffu);
-        vt[(c * 8 + 2 * e + 1) * VT4_STRIDE + key] = (bf16_t)(wds[e] >> 16);
-      }
-    }
+    char* vt = vt_base + buf * VT_BYTES;
+    const int id = tid + i * 256;
+    const int key = id / CPR, c = id % CPR;
+    *reinterpret_cast<uint4*>(ks + key * ROWB + (kswz<D>(key, c) << 4)) = kr;
+    *reinterpret_cast<uint4*>(vt + vsub_off(c >> 1) + key * 32 + (c & 1) * 16) = vr;
+  };
+  auto lstore = [&](int buf) {
+    lstore1(buf, 0, kreg0, vreg0);
+    if constexpr (CH > 1) lstore1(buf, 1, kreg1, vreg1);
   };
 
   gload(0);
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
     const int buf = t & 1;
     if (t + 1 < nt) gload(t + 1);                              // in flight while this tile is multiplied
     const char* ks = ks_base + buf * KS_BYTES;
-    const bf16_t* vt = vt_base + buf * (D * VT4_STRIDE);
+    const char* vt = vt_base + buf * VT_BYTES + vlane;
     const int k0 = t * 64;
     // ---- S^T for the two 32-key sub-tiles
     f32x16_t s[2];
@@ -499,13 +521,17 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s[sub], 0, 0, 0);
       }
     }
-    // ---- scores -> probabilities (fp32). The per-element work is kept minimal: one bias read at a lane-constant base
-    // + immediate offset, the key-mask add only in tiles that contain a masked / padded key, exp2 with the log2(e)
-    // factor folded into one FMA, and the O^T rescale only when some row maximum of the wave actually moved.
+    // ---- scores -> probabilities (fp32), in the LOG2 domain: x' = log2(e) * (scaled score + bias) is ONE fma per element
+    // (the bias table is pre-multiplied), p = exp2(x' - m'). The additive key mask (0 / -finfo.max / -inf) is added
+    // unscaled: it absorbs x' exactly as it absorbs x in the reference, so fully masked rows still come out uniform.
+    // The running maximum is only raised when some row's tile maximum exceeds it by more than 2^8 (softmax is
+    // invariant to the reference point; p <= 256 keeps bf16 relative precision and fp32 sums exact enough), which
+    // removes the O^T rescale from almost every tile.
     float x[2][16];
     float mt = -INFINITY;
     const bool masked_tile = tflag[t] != 0;                    // workgroup-uniform
     const float* bq = btab + (boff - qi + k0 + 4 * hi);        // T5: bias of key (k0 + 4hi + j) is bq[j]
+    const float csc = (MODE == ATTN_T5 ? 1.0f : p.scale) * kLog2e;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -515,9 +541,9 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
         for (int e = 0; e < 4; ++e) {
           const float sv = s[sub][4 * g + e];
           float v;
-          if (MODE == ATTN_T5) v = sv + bq[kl + e];
-          else if (MODE == ATTN_CROSS) v = sv * p.scale;
-          else v = (k0 + kl + 4 * hi + e > qi) ? -1e4f : sv * p.scale;
+          if (MODE == ATTN_T5) v = __builtin_fmaf(sv, csc, bq[kl + e]);
+          else if (MODE == ATTN_CROSS) v = sv * csc;
+          else v = (k0 + kl + 4 * hi + e > qi) ? -1e4f * kLog2e : sv * csc;
           x[sub][4 * g + e] = v;
         }
       }
@@ -528,8 +554,6 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 ma = *reinterpret_cast<const float4*>(madd + k0 + sub * 32 + 8 * g + 4 * hi);
-          // reference order of operations: T5 adds (bias + mask) to the score, the others add the mask last; for the
-          // values involved (0 or -finfo.max / -inf) both orders round identically
           x[sub][4 * g + 0] += ma.x; x[sub][4 * g + 1] += ma.y; x[sub][4 * g + 2] += ma.z; x[sub][4 * g + 3] += ma.w;
         }
     }
@@ -538,24 +562,9 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, x[sub][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    // exp(x - m) = exp2((x - m) * log2 e). (x - m) is formed first: with the reference's finfo.min masks, m itself can be
-    // -finfo.max (fully masked row) and m * log2(e) would overflow.
-    constexpr float kLog2e = 1.4426950408889634f;
-    uint32_t pk[2][8];
-    float rs = 0.f;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f((x[sub][r] - m_new) * kLog2e);
-        const float p1 = __builtin_amdgcn_exp2f((x[sub][r + 1] - m_new) * kLog2e);
-        pk[sub][r >> 1] = pack2_bf16(p0, p1);
-        rs += p0 + p1;
-      }
-    rs += __shfl_xor(rs, 32, 64);
-    if (__any(m_new != m_run)) {                               // wave-uniform: some row maximum moved
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+    if (__any(mt > m_run + 8.0f)) {                            // wave-uniform, rare after the first tiles
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
       l_run *= alpha;
 #pragma unroll
       for (int it = 0; it < OT; ++it)
@@ -563,6 +572,18 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
         for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
       m_run = m_new;
     }
+    uint32_t pk[2][8];
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(x[sub][r] - m_run);
+        const float p1 = __builtin_amdgcn_exp2f(x[sub][r + 1] - m_run);
+        pk[sub][r >> 1] = pack2_bf16(p0, p1);
+        rs += p0 + p1;
+      }
+    rs += __shfl_xor(rs, 32, 64);
     l_run += rs;
     // ---- O^T += V^T . P^T
 #pragma unroll
@@ -574,9 +595,10 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
 #pragma unroll
         for (int it = 0; it < OT; ++it) {
-          const bf16_t* vr = vt + (it * 32 + l31) * VT4_STRIDE + sub * 32 + 16 * half + 4 * hi;
-          const uint2 a0 = *reinterpret_cast<const uint2*>(vr);
-          const uint2 a1 = *reinterpret_cast<const uint2*>(vr + 8);
+          // keys sub*32 + half*16 + 4 hi + {0..3 | 8..11}, d = it*32 + l31
+          const char* vr = vt + vsub_off(2 * it) + (sub * 32 + half * 16) * 32;
+          const uint2 a0 = lds_read_tr16(vr);
+          const uint2 a1 = lds_read_tr16(vr + 8 * 32);
           uint4 vu;
           vu.x = a0.x; vu.y = a0.y; vu.z = a1.x; vu.w = a1.y;
           ot[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vu), pf, ot[it], 0, 0, 0);
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
   constexpr int VT_BYTES = D * VTS * 2;
   constexpr int CH = SPLIT_TK * CPR / 256;                     // 16-B chunks per thread per tile
   char* ks_base = smems;
-  bf16_t* vt_base = reinterpret_cast<bf16_t*>(smems + 2 * KS_BYTES);
+  char* vt_base = smems + 2 * KS_BYTES;                      // [2] x V image: D/16 sub-tiles of [128 keys][16 d]
   float* madd = reinterpret_cast<float*>(smems + 2 * KS_BYTES + 2 * VT_BYTES);
   const int nt = (p.Lk + SPLIT_TK - 1) / SPLIT_TK;
 
@@ -653,44 +675,49 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
     for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  uint4 kreg[CH], vreg[CH];
+  // staging registers (named scalars: arrays captured by the lambdas stay in scratch memory, see attn_mfma4_kernel)
+  static_assert(CH == 2 || CH == 4, "staging registers");
+  uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+  auto gaddr = [&](int t, int i, const bf16_t* base, int ld) {
+    const int id = tid + i * 256;
+    const int key = id / CPR, c = id % CPR;
+    int row = t * SPLIT_TK + key;
+    row = row < p.Lk ? row : p.Lk - 1;
+    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lk + row) * ld + h * D + c * 8);
+  };
   auto gload = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int id = tid + i * 256;
-      const int key = id / CPR, c = id % CPR;
-      int row = t * SPLIT_TK + key;
-      row = row < p.Lk ? row : p.Lk - 1;
-      kreg[i] = *reinterpret_cast<const uint4*>(K + ((long long)b * p.Lk + row) * p.ldk + h * D + c * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lk + row) * p.ldv + h * D + c * 8);
+    kreg0 = *gaddr(t, 0, K, p.ldk); vreg0 = *gaddr(t, 0, V, p.ldv);
+    kreg1 = *gaddr(t, 1, K, p.ldk); vreg1 = *gaddr(t, 1, V, p.ldv);
+    if constexpr (CH > 2) {
+      kreg2 = *gaddr(t, 2, K, p.ldk); vreg2 = *gaddr(t, 2, V, p.ldv);
+      kreg3 = *gaddr(t, 3, K, p.ldk); vreg3 = *gaddr(t, 3, V, p.ldv);
     }
+  };
+  auto lstore1 = [&](int buf, int i, const uint4& kr, const uint4& vr) {
+    const int id = tid + i * 256;
+    const int key = id / CPR, c = id % CPR;
+    *reinterpret_cast<uint4*>(ks_base + buf * KS_BYTES + key * ROWB + (kswz<D>(key, c) << 4)) = kr;
+    *reinterpret_cast<uint4*>(vt_base + buf * VT_BYTES + vsub_off<SPLIT_TK>(c >> 1) + key * 32 + (c & 1) * 16) = vr;
   };
   auto lstore = [&](int buf) {
-    char* ks = ks_base + buf * KS_BYTES;
-    bf16_t* vt = vt_base + buf * (D * VTS);
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int id = tid + i * 256;
-      const int key = id / CPR, c = id % CPR;
-      *reinterpret_cast<uint4*>(ks + key * ROWB + (kswz<D>(key, c) << 4)) = kreg[i];
-      const uint32_t wds[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vt[(c * 8 + 2 * e) * VTS + key] = (bf16_t)(wds[e] & 0xffffu);
-        vt[(c * 8 + 2 * e + 1) * VTS + key] = (bf16_t)(wds[e] >> 16);
-      }
+    lstore1(buf, 0, kreg0, vreg0);
+    lstore1(buf, 1, kreg1, vreg1);
+    if constexpr (CH > 2) {
+      lstore1(buf, 2, kreg2, vreg2);
+      lstore1(buf, 3, kreg3, vreg3);
     }
   };
+  // transposing V reads (see attn_mfma4_kernel): 16-lane group g reads sub-tile g&1, keys 4 hi + i/4, column quad i%4
+  const int vlane = vsub_off<SPLIT_TK>((lane >> 4) & 1) + (w * 32 + 4 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
   gload(0);
   lstore(0);
   __syncthreads();
-  constexpr float kLog2e = 1.4426950408889634f;
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) gload(t + 1);
     const char* ks = ks_base + buf * KS_BYTES;
-    const bf16_t* vt = vt_base + buf * (D * VTS);
+    const char* vt = vt_base + buf * VT_BYTES + vlane;
     const int kb = t * SPLIT_TK + w * 32;                      // first key of this wave's quarter
     if (kb < p.Lk) {                                           // wave-uniform: quarter not entirely beyond the keys
       f32x16_t s;
@@ -702,8 +729,10 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
         const uint4 u = *reinterpret_cast<const uint4*>(ks + row * ROWB + (kswz<D>(row, dd * 2 + hi) << 4));
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s, 0, 0, 0);
       }
+      // log2-domain softmax with a lazily raised running maximum (see attn_mfma4_kernel)
       float x[16];
       float mt = -INFINITY;
+      const float csc = p.scale * kLog2e;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int key = kb + 8 * g + 4 * hi;
@@ -711,27 +740,17 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
         const float mav[4] = {ma.x, ma.y, ma.z, ma.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = s[4 * g + e] * p.scale;
-          if (MODE == ATTN_CAUSAL && key + e > qi) v = -1e4f;
+          float v = s[4 * g + e] * csc;
+          if (MODE == ATTN_CAUSAL && key + e > qi) v = -1e4f * kLog2e;
           v = v + mav[e];
           x[4 * g + e] = v;
           mt = fmaxf(mt, v);
         }
       }
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);                    // finite: key kb is in range
-      uint32_t pk[8];
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f((x[r] - m_new) * kLog2e);
-        const float p1 = __builtin_amdgcn_exp2f((x[r + 1] - m_new) * kLog2e);
-        pk[r >> 1] = pack2_bf16(p0, p1);
-        rs += p0 + p1;
-      }
-      rs += __shfl_xor(rs, 32, 64);
-      if (__any(m_new != m_run)) {
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+      if (__any(mt > m_run + 8.0f)) {
+        const float m_new = fmaxf(m_run, mt);                  // finite: key kb is in range
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         l_run *= alpha;
 #pragma unroll
         for (int it = 0; it < OT; ++it)
@@ -739,6 +758,16 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
           for (int r = 0; r < 16; ++r) ot[it][r] *= alpha;
         m_run = m_new;
       }
+      uint32_t pk[8];
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(x[r] - m_run);
+        const float p1 = __builtin_amdgcn_exp2f(x[r + 1] - m_run);
+        pk[r >> 1] = pack2_bf16(p0, p1);
+        rs += p0 + p1;
+      }
+      rs += __shfl_xor(rs, 32, 64);
       l_run += rs;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -747,9 +776,9 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
 #pragma unroll
         for (int it = 0; it < OT; ++it) {
-          const bf16_t* vr = vt + (it * 32 + l31) * VTS + w * 32 + 16 * half + 4 * hi;
-          const uint2 a0 = *reinterpret_cast<const uint2*>(vr);
-          const uint2 a1 = *reinterpret_cast<const uint2*>(vr + 8);
+          const char* vr = vt + vsub_off<SPLIT_TK>(2 * it) + (half * 16) * 32;
+          const uint2 a0 = lds_read_tr16(vr);
+          const uint2 a1 = lds_read_tr16(vr + 8 * 32);
           uint4 vu;
           vu.x = a0.x; vu.y = a0.y; vu.z = a1.x; vu.w = a1.y;
           ot[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vu), pf, ot[it], 0, 0, 0);
@@ -780,7 +809,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
     float sc[4], l_all = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sc[j] = __builtin_amdgcn_exp2f((mw[j] - m_all) * kLog2e);   // a wave that saw no key has m = -inf -> weight 0
+      sc[j] = __builtin_amdgcn_exp2f(mw[j] - m_all);   // a wave that saw no key has m = -inf -> weight 0
       l_all += comb[(j * NV + OT * 16 + 1) * 64 + lane] * sc[j];
     }
     const float inv = 1.0f / l_all;
