@@ -44,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     pr = pol.prof_read()["gemm"]
     if os.environ.get("STAMPS"):
-        nblk = ((M + 255) // 256 + 7) // 8 * 8 * ((N + 255) // 256) if tile in (2, 4, 5, 6) else ((M + 127) // 128 + 7) // 8 * 8 * ((N + 127) // 128)
+        nblk = ((M + 255) // 256 + 7) // 8 * 8 * ((N + 255) // 256) if tile in (2, 4, 5, 6) or (tile == 0 and M >= 8192) else ((M + 127) // 128 + 7) // 8 * 8 * ((N + 127) // 128)
         dbg = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
         pol.set_option("gemm_dbg_ptr", dbg.data_ptr())
         _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, 0, p(out), pol._stream()))

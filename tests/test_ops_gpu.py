@@ -82,13 +82,16 @@ def test_linear_bf16_output_path(M, N, K, tile):
         pol.set_option("op_bf16_out", 0)
 
 
-@pytest.mark.parametrize("tile", [2, 3, 4, 5, 6])
-@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (256, 256, 64), (1000, 1300, 3072), (77, 520, 1536), (300, 200, 128)])
-def test_linear_large_tile(M, N, K, tile):
-    """The 256x256 / 8-wave (tile 2) and 256x128 / 3-stage-ring (tile 3) paths (bf16), forced on shapes with ragged
-    edges and short K (fewer slices than ring stages); same epilogues."""
+@pytest.mark.parametrize("tile,persist", [(2, 0), (2, 1)])
+@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (256, 256, 64), (1000, 1300, 3072), (77, 520, 1536), (300, 200, 128),
+                                   (512, 768, 768), (2816, 512, 3072), (256, 256, 128)])   # full tiles: persistent kernel
+def test_linear_large_tile(M, N, K, tile, persist):
+    """The 256x256 / 8-wave tile (bf16) as one-tile-per-workgroup kernel and as the persistent kernel, forced on shapes
+    with ragged edges and short K (fewer slices than ring stages falls back to the non-persistent kernel); same
+    epilogues."""
     pol = bare_policy("bf16")
     pol.set_option("gemm_tile", tile)
+    pol.set_option("gemm_persist", persist)
     try:
         g = torch.Generator().manual_seed(M + N + K)
         for act, use_b, use_m, use_r in [(0, 0, 0, 0), (3, 1, 0, 1), (2, 1, 1, 0), (1, 1, 0, 0)]:
@@ -114,6 +117,7 @@ def test_linear_large_tile(M, N, K, tile):
             assert max_rel(out, ref) < 2e-3, (act, use_b, use_m, use_r)
     finally:
         pol.set_option("gemm_tile", 0)
+        pol.set_option("gemm_persist", 1)
 
 
 def test_linear_transpose_detecting():

@@ -116,6 +116,25 @@ def test_dual_stream_and_pruning_are_exact():
             assert torch.equal(o[k], outs[0][k]), k
 
 
+def test_t5_fused_rmsnorm_matches_unfused():
+    """T5 RMSNorms folded into the neighbouring GEMMs (weight in W, statistics from the producer's epilogue, row scale in
+    the consumer's) against the standalone RMSNorm kernel path: same maths, different rounding points. fp32 operands
+    agree to ~1e-6; bf16 operands within the usual bf16 bounds; the fused path is deterministic (no atomics)."""
+    cfg, wseed, prompts, obs, actions = build_case("e384_long")
+    sd = syn.make_state_dict(cfg, wseed)
+    for prec, tok_tol in (("fp32", 2e-5), ("bf16", 4e-2)):
+        outs = {}
+        for fuse in (0, 1):
+            pol = loaded_policy(cfg, sd, prec, t5_fuse_rms=fuse)
+            outs[fuse] = native_outputs(pol, prompts, obs, actions)
+            if fuse:
+                again = native_outputs(pol, prompts, obs, actions)
+                for k in ("prompt_tokens", "predicted", "raw_logits"):
+                    assert torch.equal(again[k], outs[1][k]), (prec, k)
+        assert max_rel(outs[1]["prompt_tokens"], outs[0]["prompt_tokens"]) < tok_tol, prec
+        assert max_abs(outs[1]["raw_logits"], outs[0]["raw_logits"]) < (1e-5 if prec == "fp32" else 1e-3), prec
+
+
 def test_prompt_kv_cache_is_exact_and_invalidates():
     """Cross-step caching of the per-layer prompt K/V: passing the same prompt tensor again reuses
     the cache and must give bit-identical tokens; an in-place edit of the prompt (version counter) or a new tensor

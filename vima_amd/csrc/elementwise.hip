@@ -345,6 +345,24 @@ __global__ __launch_bounds__(256) void gather_pred_kernel(const float* __restric
   *reinterpret_cast<float4*>(out + tb * E + c) = *reinterpret_cast<const float4*>(x + ((long long)b * Lq + l) * E + c);
 }
 
+// Entry of the fused-RMSNorm chain (T5 stack): operand-type copy of the fp32 rows + their sum of squares. One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void rms_stats_kernel(const float* __restrict__ in, int rows, int E, T* outT, float* ssq) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + (long long)row * E;
+  const int nv = E >> 2;
+  float q = 0.f;
+  for (int c = lane; c < nv; c += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(x + c * 4);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    store4(outT + (long long)row * E + c * 4, v);
+  }
+  q = wave_sum(q);
+  if (lane == 0) ssq[row] = q;
+}
+
 inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -359,6 +377,14 @@ int launch_layernorm(const float* in, long long ldin, const float* gamma, const 
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, rms,
                        rows, E, out32, (float*)outT);
+  return (int)hipGetLastError();
+}
+
+int launch_rms_stats(const float* in, int rows, int E, void* outT, float* ssq, bool is_bf16, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (E % 4 != 0) return (int)hipErrorInvalidValue;
+  if (is_bf16) hipLaunchKernelGGL(rms_stats_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, rows, E, (bf16_t*)outT, ssq);
+  else hipLaunchKernelGGL(rms_stats_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, rows, E, (float*)outT, ssq);
   return (int)hipGetLastError();
 }
 

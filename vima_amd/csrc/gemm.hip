@@ -67,10 +67,6 @@ struct Tile {
 };
 using TileS = Tile<128, 128, 2, 2, 128, 2>;   // 64 KiB, 2 workgroups / CU
 using TileL = Tile<256, 256, 2, 4, 128, 2>;   // 128 KiB, 1 workgroup / CU, 8 waves
-using TileM = Tile<256, 128, 2, 2, 64, 3>;    // 72 KiB, 2 workgroups / CU, 4 waves of 128x64, 3-deep ring of 32-wide slices
-using TileX = Tile<256, 256, 2, 2, 128, 2, 1>; // 128 KiB, 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers)
-using TileH4 = Tile<256, 256, 2, 4, 64, 4>;   // 128 KiB, 8 waves, ring of FOUR 32-wide K-slices (DMA lead 3 half-slices)
-using TileH5 = Tile<256, 256, 2, 4, 64, 5>;   // 160 KiB, ring of FIVE 32-wide K-slices (DMA lead 4 half-slices = 2x TileL)
 
 template <int RB> __device__ __forceinline__ int swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
@@ -156,6 +152,26 @@ __device__ __forceinline__ f32x16_t mma(const Frag<float>& w, const Frag<float>&
   return acc;
 }
 
+// fused RMSNorm row scale: rsqrt(mean of squares + eps) from the producer's per-64-column partial sums (fixed order)
+__device__ __forceinline__ float rms_row_scale(const float* ssq, int parts, int row, float invk, float eps) {
+  const float* q = ssq + (long long)row * parts;
+  float t;
+  if (parts == 12) {   // E = 768: three independent 16-byte loads (a scalar loop serialises twelve load latencies)
+    const float4 a = load4(q), b = load4(q + 4), c = load4(q + 8);
+    t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + ((c.x + c.y) + (c.z + c.w));
+  } else {
+    t = 0.f;
+    for (int j = 0; j < parts; ++j) t += q[j];
+  }
+  return __builtin_amdgcn_rsqf(t * invk + eps);
+}
+
+// sum of squares of 4 consecutive output columns; one fixed fma chain so that every kernel rounds identically (the
+// fused-RMSNorm statistics must not depend on which tile shape produced the row: batch-composition invariance)
+__device__ __forceinline__ float sumsq4(const float4& v) {
+  return __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+}
+
 struct GemmDev {
   const void* A; const void* W;
   int M, N, K, lda, ldw;
@@ -166,6 +182,7 @@ struct GemmDev {
   float* out32; int ld32;
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
+  float* ssq_out; const float* rs_ssq; int rs_parts; float rs_invk, rs_eps;
   int mtiles, ntiles;
   int vtotal;   // persistent kernel: number of virtual tile ids = ceil8(mtiles) * ntiles
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
@@ -425,12 +442,17 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
       const int n = n0 + wn * WCOLS + cc;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
+        float rsc = 1.0f;   // fused RMSNorm: scale of this lane's accumulator row
+        if (p.rs_ssq) {
+          int mr = m0 + wm * (MI * 32) + mi * 32 + l31; mr = mr < p.M ? mr : p.M - 1;
+          rsc = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int nl = ni * 32 + 8 * q + 4 * hi;
-            float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+            float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
             const int nb = n0 + wn * WCOLS + nl;
             if (bias && nb < p.N) { const float4 b = load4(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
@@ -471,6 +493,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           const int r = it * RPI + rr;
           float4 v = *reinterpret_cast<const float4*>(stage + r * LDE + cc);
           const int m = m0 + wm * (MI * 32) + mi * 32 + r;
+          float sq = 0.f;
           if (m < p.M && n < p.N) {
             long long orow = m;
             if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
@@ -478,6 +501,13 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
             if (out32) store4(out32 + orow * p.ld32 + n, v);
             if (outT) store4(outT + orow * p.ldT + n, v);
+            sq = sumsq4(v);
+          }
+          if (p.ssq_out) {   // wave-uniform; the LPR lanes of a row are consecutive: butterfly, one partial per row
+            static_assert(WCOLS == 64, "RMS partial sums are per 64 output columns");
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            if ((lane % LPR) == 0 && m < p.M && n < p.N) p.ssq_out[(long long)m * (p.N >> 6) + ((n0 + wn * WCOLS) >> 6)] = sq;
           }
         }
       }
@@ -501,6 +531,11 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
+        if (p.rs_ssq) {
+          const float rsc = rms_row_scale(p.rs_ssq, p.rs_parts, m, p.rs_invk, p.rs_eps);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= rsc;
+        }
         if constexpr (VEC) {   // N % 4 == 0 => n + 3 < N
           if (bias) { const float4 b = load4(bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
           if (act != ACT_NONE) {
@@ -540,7 +575,10 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // one continuous LDS-DMA stream: the first two slices of tile i+1 are requested during the last two k-slices of tile
 // i and land while tile i's epilogue runs. The epilogue stages through its own 32 KiB of LDS (32x32 fp32 slabs per
 // wave, XOR-swizzled: conflict-free for ds_write_b128 and both read-back shapes), so both ring stages stay free.
-template <int ACT>
+// EPI specialises the epilogue at compile time (fewer live scalars / registers than the all-runtime form, which spilled):
+//   (0 = every feature a runtime flag: not instantiated) 1 bf16-only output, optional bias / fused-RMSNorm row scale
+//   2 bf16-only output x gate (`mul`: GEGLU)      3 residual add with fp32 (+ optional bf16) output, optional RMS partials
+template <int ACT, int EPI>
 __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(const GemmDev p) {
   using T = bf16_t;
   using TL = TileL;
@@ -580,7 +618,9 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
   };
 
   // ---- issue cursor: the (tile, K-slice) the next LDS-DMA slice belongs to; runs up to two slices ahead of the MFMAs
-  // per-lane BYTE offsets from A / W (launcher guarantees they fit 32 bits); the k-slice offset is added at issue
+  // per-lane BYTE offsets from A / W (SADDR-form LDS-DMA: uniform 64-bit base + unsigned 32-bit lane offset; the
+  // launcher guarantees they fit); the k-slice offset is added at issue. The launcher only sends problems with
+  // M % 256 == 0 and N % 256 == 0 here, so no row needs clamping.
   unsigned offA[TL::PA], offW[TL::PW];
   int iv, ikt = 0;
   const int r0 = (w * 64 + lane) / CPR;                 // row of this lane within a 64-row piece group
@@ -589,15 +629,11 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     int tm, tn;
     tile_at(v, tm, tn);
 #pragma unroll
-    for (int i = 0; i < TL::PA; ++i) {
-      int ra = tm * TL::BM + i * (NW * 64 / CPR) + r0; ra = ra < p.M ? ra : p.M - 1;
-      offA[i] = (unsigned)ra * (unsigned)(p.lda * (int)sizeof(T)) + c0;
-    }
+    for (int i = 0; i < TL::PA; ++i)
+      offA[i] = (unsigned)(tm * TL::BM + i * (NW * 64 / CPR) + r0) * (unsigned)(p.lda * (int)sizeof(T)) + c0;
 #pragma unroll
-    for (int i = 0; i < TL::PW; ++i) {
-      int rw = tn * TL::BN + i * (NW * 64 / CPR) + r0; rw = rw < p.N ? rw : p.N - 1;
-      offW[i] = (unsigned)rw * (unsigned)(p.ldw * (int)sizeof(T)) + c0;
-    }
+    for (int i = 0; i < TL::PW; ++i)
+      offW[i] = (unsigned)(tn * TL::BN + i * (NW * 64 / CPR) + r0) * (unsigned)(p.ldw * (int)sizeof(T)) + c0;
   };
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto issue_piece = [&](int stage, int j) {
@@ -652,6 +688,17 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
       }
     };
     stamp(0);
+    // fused RMSNorm: scales of this lane's four accumulator rows, fetched at the START of the tile (the wave is about to
+    // wait for its first K-slice anyway; in the epilogue the same loads would queue behind the next tile's LDS-DMA)
+    float rscv[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      rscv[mi] = 1.0f;
+      if ((EPI == 0 || EPI == 1) && p.rs_ssq) {
+        int mr = m0 + wm * (MI * 32) + mi * 32 + l31; mr = mr < p.M ? mr : p.M - 1;
+        rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
+      }
+    }
     f32x16_t acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -737,8 +784,14 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
     auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
     float* stg = reinterpret_cast<float*>(smem + EPI_OFF + w * 4096);
-    const T* mul = reinterpret_cast<const T*>(p.mul);
+    const bool wide8 = EPI == 0 ? p.wide8 != 0 : (EPI == 1 || EPI == 2);
+    const T* mul = (EPI == 0 || EPI == 2) ? reinterpret_cast<const T*>(p.mul) : nullptr;
+    const float* res = (EPI == 0 || EPI == 3) ? p.res : nullptr;
+    float* out32 = (EPI == 0 || EPI == 3) ? p.out32 : nullptr;
     T* outT = reinterpret_cast<T*>(p.outT);
+    const float* rs_ssq = (EPI == 0 || EPI == 1) ? p.rs_ssq : nullptr;
+    float* ssq_out = (EPI == 0 || EPI == 3) ? p.ssq_out : nullptr;
+    const int rb = EPI == 0 ? p.rb : 0;
     // the epilogue's per-lane address arithmetic is tile-invariant: hipcc would hoist it out of the tile loop and keep
     // (spill) it across the main loop. An opaque copy of the lane id pins it here.
     int elane = lane;
@@ -747,39 +800,48 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     const int fw_ = fsw(el31);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      const float rsc = rscv[mi];
+      float sqrow[4] = {0.f, 0.f, 0.f, 0.f};   // per row (it*8 + lane/8) sum of squares over the wave's 64 columns
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int nbase = n0 + wn * (NI * 32) + ni * 32;
         const int mbase = m0 + wm * (MI * 32) + mi * 32;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+          float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
           const int nb = nbase + 8 * q + 4 * ehi;
           if (p.bias && nb < p.N) { const float4 b = load4(p.bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
           if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
           *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
         }
-        if (p.wide8) {   // bf16-only output: 4 lanes x 16 B per row, 16 rows per instruction
+        // read-back, software-pipelined by one row group: the gate / residual loads of group it+1 are issued BEFORE the
+        // stores of group it (a load issued behind stores waits for them to drain: vmcnt retires in order)
+        if (wide8) {   // bf16-only output: 4 lanes x 16 B per row, 16 rows per instruction
           const int c8 = elane & 3;
           const int n8 = nbase + c8 * 8;
+          float4 g0n, g1n, r0n, r1n;
+          auto load_aux = [&](int it) {
+            const int m = mbase + it * 16 + (elane >> 2);
+            if (m < p.M && n8 < p.N) {
+              if (mul) { g0n = load4(mul + (long long)m * p.ldmul + n8); g1n = load4(mul + (long long)m * p.ldmul + n8 + 4); }
+              if (res) { r0n = load4(res + (long long)m * p.ldres + n8); r1n = load4(res + (long long)m * p.ldres + n8 + 4); }
+            }
+          };
+          load_aux(0);
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             const int r = it * 16 + (elane >> 2);
             const int f = fsw(r);
             float4 v0 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8) ^ f) << 2));
             float4 v1 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8 + 1) ^ f) << 2));
+            const float4 g0 = g0n, g1 = g1n, r0 = r0n, r1 = r1n;
+            if (it + 1 < 2) load_aux(it + 1);
             const int m = mbase + r;
             if (m < p.M && n8 < p.N) {
               long long orow = m;
-              if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
-              if (mul) {
-                const float4 g0 = load4(mul + (long long)m * p.ldmul + n8), g1 = load4(mul + (long long)m * p.ldmul + n8 + 4);
-                v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w; v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
-              }
-              if (p.res) {
-                const float4 r0 = load4(p.res + (long long)m * p.ldres + n8), r1 = load4(p.res + (long long)m * p.ldres + n8 + 4);
-                v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
-              }
+              if (rb > 0) orow = (long long)(m / rb) * p.s_hi + (long long)(m % rb) * p.s_lo + p.ro;
+              if (mul) { v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w; v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w; }
+              if (res) { v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w; }
               uint4 o;
               o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
               *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
@@ -788,20 +850,46 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
         } else {         // 8 lanes x 16 B (fp32) per row, 8 rows per instruction
           const int cc = elane & 7;
           const int n = nbase + cc * 4;
+          float4 gn, rn;
+          auto load_aux = [&](int it) {
+            const int m = mbase + it * 8 + (elane >> 3);
+            if (m < p.M && n < p.N) {
+              if (mul) gn = load4(mul + (long long)m * p.ldmul + n);
+              if (res) rn = load4(res + (long long)m * p.ldres + n);
+            }
+          };
+          load_aux(0);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int r = it * 8 + (elane >> 3);
             float4 v = *reinterpret_cast<const float4*>(stg + r * 32 + ((cc ^ fsw(r)) << 2));
+            const float4 g = gn, r4 = rn;
+            if (it + 1 < 4) load_aux(it + 1);
             const int m = mbase + r;
+            float sq = 0.f;
             if (m < p.M && n < p.N) {
               long long orow = m;
-              if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
-              if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
-              if (p.res) { const float4 r4 = load4(p.res + (long long)m * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
-              if (p.out32) store4(p.out32 + orow * p.ld32 + n, v);
+              if (rb > 0) orow = (long long)(m / rb) * p.s_hi + (long long)(m % rb) * p.s_lo + p.ro;
+              if (mul) { v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
+              if (res) { v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+              if (out32) store4(out32 + orow * p.ld32 + n, v);
               if (outT) store4(outT + orow * p.ldT + n, v);
+              sq = sumsq4(v);
+            }
+            if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly in the canonical order
+              sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+              sqrow[it] = ni == 0 ? sq : sqrow[it] + sq;   // (columns 0-31) + (columns 32-63): the xor-8 stage of a 16-lane row
             }
           }
+        }
+      }
+      if (ssq_out) {   // one partial per row and 64-column slab (plain store: deterministic)
+        const int mbase = m0 + wm * (MI * 32) + mi * 32;
+        const int nslab = n0 + wn * (NI * 32);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = mbase + it * 8 + (elane >> 3);
+          if ((elane & 7) == 0 && m < p.M && nslab < p.N) ssq_out[(long long)m * (p.N >> 6) + (nslab >> 6)] = sqrow[it];
         }
       }
     }
@@ -813,7 +901,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 
 // 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin (TileS only). Override with VIMA_GEMM_VARIANT.
 int g_gemm_variant = -1;
-int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL, 3 force TileM (bf16 only)
+int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL (bf16 only)
 int g_gemm_raster = -1; // see GemmDev::raster
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -882,17 +970,17 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
 int g_gemm_persist = -1;   // 1 (default): large bf16 GEMMs run on the persistent kernel; VIMA_GEMM_PERSIST / option gemm_persist
 int g_num_cu = 0;
 
-template <int ACT>
+template <int ACT, int EPI>
 int launch_persistent_inst(const GemmDev& d, int grid, hipStream_t st) {
   constexpr int SMEM = TileL::SMEM_BYTES + TileL::NW * 4096;   // ring + epilogue slabs = 160 KiB
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_persistent_kernel<ACT>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
+  hipLaunchKernelGGL((gemm_persistent_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
   return (int)hipGetLastError();
 }
 
@@ -909,12 +997,20 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
   d.dbg = g_gemm_dbg;
   const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
-  switch (a.act) {
-    case ACT_NONE: return launch_persistent_inst<ACT_NONE>(d, grid, st);
-    case ACT_RELU: return launch_persistent_inst<ACT_RELU>(d, grid, st);
-    case ACT_GELU: return launch_persistent_inst<ACT_GELU>(d, grid, st);
-    case ACT_QUICKGELU: return launch_persistent_inst<ACT_QUICKGELU>(d, grid, st);
-    default: return (int)hipErrorInvalidValue;
+  // specialised epilogues for the combinations the policy uses; everything else takes the generic instantiation
+  int epi = 0;
+  if (a.rb == 0) {
+    if (d.wide8 && !a.mul && !a.res && !a.ssq_out) epi = 1;
+    else if (d.wide8 && a.mul && !a.res && !a.rs_ssq && !a.ssq_out) epi = 2;
+    else if (!d.wide8 && a.res && a.out32 && !a.mul && !a.rs_ssq) epi = 3;
+  }
+  switch (a.act * 4 + epi) {
+    case ACT_NONE * 4 + 1: return launch_persistent_inst<ACT_NONE, 1>(d, grid, st);
+    case ACT_NONE * 4 + 3: return launch_persistent_inst<ACT_NONE, 3>(d, grid, st);
+    case ACT_RELU * 4 + 1: return launch_persistent_inst<ACT_RELU, 1>(d, grid, st);
+    case ACT_GELU * 4 + 2: return launch_persistent_inst<ACT_GELU, 2>(d, grid, st);
+    case ACT_QUICKGELU * 4 + 1: return launch_persistent_inst<ACT_QUICKGELU, 1>(d, grid, st);
+    default: return -1;   // no specialised instantiation (the all-runtime form spills): one-tile-per-workgroup kernel
   }
 }
 
@@ -944,6 +1040,9 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
+  d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
+  if (a.ssq_out && (!a.out32 || a.batch > 1 || a.N % 64 != 0)) return (int)hipErrorInvalidValue;
+  if (a.rs_ssq && a.rs_parts <= 0) return (int)hipErrorInvalidValue;
   d.mtiles = d.ntiles = 0;
   bool v = (a.N % 4 == 0);
   if (a.bias) v = v && aligned_to(a.bias, 16) && (a.bsBias % 4 == 0);
@@ -963,14 +1062,13 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 224) && waste < 1.15;
     if (gemm_tile() == 1) large = false;
     if (gemm_tile() >= 2) large = v;
-    if (large && gemm_tile() == 3) return launch_tile<T, TileM, true>(d, a, v, st);
-    if (large && gemm_tile() == 4) return launch_tile<T, TileX, true>(d, a, v, st);
-    if (large && gemm_tile() == 5) return launch_tile<T, TileH4, true>(d, a, v, st);
-    if (large && gemm_tile() == 6) return launch_tile<T, TileH5, true>(d, a, v, st);
     if (large && (gemm_tile() == 0 || gemm_tile() == 2) && env_cached("VIMA_GEMM_PERSIST", g_gemm_persist, 1) && a.batch <= 1 &&
         a.K >= 2 * 64 && gemm_raster() == 0 && env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1) &&
-        (long long)a.M * a.lda * 2 < (1LL << 32) && (long long)a.N * a.ldw * 2 < (1LL << 32))
-      return launch_persistent(d, a, st);
+        a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
+        (long long)a.N * a.ldw * 2 < (1LL << 32)) {
+      const int e = launch_persistent(d, a, st);
+      if (e >= 0) return e;
+    }
     if (large) return launch_tile<T, TileL, true>(d, a, v, st);
   }
   if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);

@@ -28,6 +28,15 @@ struct GemmArgs {
   int ldT = 0;
   // output-row remap (outputs only): orow = (r / rb) * s_hi + (r % rb) * s_lo + ro ; rb == 0 -> identity
   int rb = 0, s_hi = 0, s_lo = 0, ro = 0;
+  // RMS statistics fused into the GEMMs either side of a T5 RMSNorm (the norm's weight is folded into W at pack time):
+  //   producer: ssq_out[r][j] = sum over columns [64j, 64j+64) of out[r][n]^2 (final fp32 values; needs out32, N % 64 == 0,
+  //             batch 1). Plain stores of N/64 partials per row -- no atomics, so the result is deterministic.
+  //   consumer: accumulator row r is multiplied by rsqrt((sum_j rs_ssq[r][j], j < rs_parts) * rs_invk + rs_eps) before
+  //             bias / activation
+  float* ssq_out = nullptr;
+  const float* rs_ssq = nullptr;
+  int rs_parts = 0;
+  float rs_invk = 0.f, rs_eps = 0.f;
 };
 // returns hipError_t as int; is_bf16 selects the operand type
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
@@ -37,7 +46,7 @@ void set_gemm_raster(int v);        // tile order: 0 XCD x n-walk, 1 XCD x resid
 void set_gemm_epi(int v);           // 1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
 void set_gemm_persist(int v);       // 1 = large bf16 GEMMs on the persistent (one workgroup per CU) kernel (default), 0 = one tile per workgroup
 void set_gemm_dbg(long long* p);     // debug: device buffer [blocks*4] of shader-clock stamps (nullptr = off)
-void set_gemm_tile(int v);          // 0 = auto, 1 = 128x128 (TileS), 2 = 256x256 8 waves (TileL), 3 = 256x128 ring (TileM), 4 = 256x256 4 waves (TileX)
+void set_gemm_tile(int v);          // 0 = auto, 1 = 128x128 (TileS), 2 = 256x256 8 waves (TileL; persistent kernel unless gemm_persist=0)
 
 // ---------------------------------------------------------------- normalisation / elementwise
 // LayerNorm (rms=0: mean/var, affine) or T5 RMSNorm (rms=1: no mean, no bias). fp32 statistics.
@@ -45,6 +54,9 @@ void set_gemm_tile(int v);          // 0 = auto, 1 = 128x128 (TileS), 2 = 256x25
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
 int launch_cast(const float* in, void* outT, long long n, bool is_bf16, hipStream_t st);
+// operand-type copy of fp32 rows + their sum of squares (entry point of the fused-RMSNorm chain): outT[r][:] = in[r][:],
+// ssq[r] = sum in[r][:]^2
+int launch_rms_stats(const float* in, int rows, int E, void* outT, float* ssq, bool is_bf16, hipStream_t st);
 
 // uint8 crops [M,3,32,32] -> normalised patch matrix T [M*4, 768], k = c*256 + py*16 + px (conv1 weight order)
 int launch_patchify(const uint8_t* crops, void* outT, int M, bool is_bf16, hipStream_t st);

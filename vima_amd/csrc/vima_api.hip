@@ -126,6 +126,7 @@ struct VimaHandle {
   int attn_impl = 1;
   int vit_chunk = 16384;
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
+  int t5_fuse_rms = 1;      // T5 RMSNorms folded into the neighbouring GEMMs (statistics in the producer epilogue, row scale in the consumer)
   int op_bf16_out = 0;      // vima_op_linear: route the result through the operand-type output (tests the T store paths)
   int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
                             // GEMM epilogues) of one half overlap the MFMA-bound GEMM main loops of the other half
@@ -152,7 +153,7 @@ struct VimaHandle {
   Lin fuse; float* ee_table = nullptr;           // [2][E]
   Lin pobj[3];
   float* word_table = nullptr;                   // [32128,768] fp32
-  struct T5Layer { float *rms1, *rms2; Lin qkv, o, wi, wo; };
+  struct T5Layer { float *rms1, *rms2; Lin qkv, o, wi, wo; Lin qkv_g, wi_g; };   // *_g: RMSNorm weight folded in (W diag(g))
   T5Layer t5[kT5Layers];
   float* t5_final = nullptr;
   std::vector<float> t5_relbias_host;            // [32][12]
@@ -347,9 +348,27 @@ int pack_all(VimaHandle* h) {
       t.insert(t.end(), vv->data.begin(), vv->data.end());
       L.qkv.N = 3 * inner; L.qkv.K = kT5Model;
       L.qkv.W = P.up_T(t);
+      // (x_hat * g) W^T = x_hat (W diag(g))^T : the RMSNorm weight folded into the consumer (fused-RMSNorm path)
+      if (const HostParam* g = P.get(a + "layer_norm.weight", {kT5Model})) {
+        for (size_t n = 0; n < (size_t)3 * inner; ++n)
+          for (int k = 0; k < kT5Model; ++k) t[n * kT5Model + k] *= g->data[k];
+        L.qkv_g.N = 3 * inner; L.qkv_g.K = kT5Model;
+        L.qkv_g.W = P.up_T(t);
+      }
     }
     L.o = P.linear(a + "SelfAttention.o", kT5Model, inner, false);
     L.wi = P.linear(f + "DenseReluDense.wi", kT5FF, kT5Model, false);
+    {
+      const HostParam* w = P.get(f + "DenseReluDense.wi.weight", {kT5FF, kT5Model});
+      const HostParam* g = P.get(f + "layer_norm.weight", {kT5Model});
+      if (w && g) {
+        std::vector<float> t(w->data);
+        for (size_t n = 0; n < (size_t)kT5FF; ++n)
+          for (int k = 0; k < kT5Model; ++k) t[n * kT5Model + k] *= g->data[k];
+        L.wi_g.N = kT5FF; L.wi_g.K = kT5Model;
+        L.wi_g.W = P.up_T(t);
+      }
+    }
     L.wo = P.linear(f + "DenseReluDense.wo", kT5Model, kT5FF, false);
   }
   if (const HostParam* p = P.get(t5 + "block.0.layer.0.SelfAttention.relative_attention_bias.weight", {kT5Buckets, kT5Heads}))
@@ -698,7 +717,7 @@ int t5_bias_table(VimaHandle* h, int L, float** out) {
   return 0;
 }
 
-struct T5Buf { void *hT, *qkv, *ctx, *u; };
+struct T5Buf { void *hT, *qkv, *ctx, *u; float *ssA, *ssB; };   // ssA / ssB: RMS partial sums [rows][12] (fused path)
 
 void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B, int L,
               const T5Buf& b, int attn_impl) {
@@ -719,6 +738,42 @@ void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* ma
   R.linear(b.u, kT5FF, Ly.wo, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
 }
 
+// Same layer with both RMSNorms (T5LayerNorm: x * rsqrt(mean(x^2) + eps) * g, HF modeling_t5) folded into the GEMMs:
+//   * g lives in the consumer's weight (W diag(g), packed once),
+//   * the consumer reads the operand-type copy of the residual stream x (b.hT) that the PRODUCER of x wrote next to
+//     the fp32 stream, and scales its accumulator rows by rsqrt(sum x^2 / 768 + eps),
+//   * sum x^2 comes from the producer's epilogue as 12 per-64-column partials per row (deterministic, no atomics).
+// Entry: b.hT / ssq_in describe the incoming x (`parts_in` partials per row); exit: b.hT and the returned buffer
+// describe the outgoing x (12 partials). Removes two 600-MB HBM passes (fp32 read + bf16 write) per layer at cfg-3.
+const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B,
+                            int L, const T5Buf& b, int attn_impl, const float* ssq_in, int parts_in) {
+  const int rows = B * L;
+  constexpr int kParts = kT5Model / 64;
+  auto gemm = [&](const void* A, int lda, const Lin& W, int act, const float* res, float* out32, void* outT, int ldT,
+                  const float* rs, int rs_parts, float* ssq_out) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W.W; g.ldw = W.K; g.M = rows; g.N = W.N; g.K = W.K; g.act = act;
+    g.res = res; g.ldres = kT5Model; g.out32 = out32; g.ld32 = kT5Model; g.outT = outT; g.ldT = ldT;
+    g.rs_ssq = rs; g.rs_parts = rs_parts; g.rs_invk = 1.0f / (float)kT5Model; g.rs_eps = 1e-6f;
+    g.ssq_out = ssq_out;
+    return R.gemm(g);
+  };
+  gemm(b.hT, kT5Model, Ly.qkv_g, ACT_NONE, nullptr, nullptr, b.qkv, 3 * kT5Model, ssq_in, parts_in, nullptr);
+  AttnArgs a;
+  a.q = b.qkv; a.ldq = 3 * kT5Model;
+  a.k = R.offT(b.qkv, kT5Model); a.ldk = 3 * kT5Model;
+  a.v = R.offT(b.qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
+  a.out = b.ctx; a.ldo = kT5Model;
+  a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+  a.mode = ATTN_T5;
+  R.attn(a, attn_impl);
+  // x += ctx Wo^T ; bf16 copy of the new x -> hT ; partial sums of its squares -> ssA
+  gemm(b.ctx, kT5Model, Ly.o, ACT_NONE, x, x, b.hT, kT5Model, nullptr, 0, b.ssA);
+  gemm(b.hT, kT5Model, Ly.wi_g, ACT_RELU, nullptr, nullptr, b.u, kT5FF, b.ssA, kParts, nullptr);
+  gemm(b.u, kT5FF, Ly.wo, ACT_NONE, x, x, b.hT, kT5Model, nullptr, 0, b.ssB);
+  return b.ssB;
+}
+
 // T5 encoder stack on x fp32 [B*L, 768] (updated in place); result (after final RMSNorm) -> out32 and/or outT.
 // Samples are independent, so with dual_stream the batch is split in two halves that run the 12 layers on two streams.
 int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, void* outT) {
@@ -734,14 +789,33 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     buf[i].qkv = R.wsT(rows * 3 * kT5Model);
     buf[i].ctx = R.wsT(rows * kT5Model);
     buf[i].u = R.wsT(rows * kT5FF);
+    buf[i].ssA = R.ws<float>(rows * (kT5Model / 64));
+    buf[i].ssB = R.ws<float>(rows * (kT5Model / 64));
   }
   if (R.err) return R.err;
   Run Rb{h, h->aux};
   if (dual && fork_aux(R)) return R.err = 1;
   const long long off1 = (long long)nb[0] * L;      // first row of the second half
+  const bool fused = h->t5_fuse_rms != 0;
+  const float* ss[2] = {nullptr, nullptr};
+  int parts = 1;
+  if (fused) {   // entry of the chain: operand-type copy of x and its row sums of squares (one partial per row)
+    R.other(launch_rms_stats(x, nb[0] * L, kT5Model, buf[0].hT, buf[0].ssB, h->bf16, R.st), "rms_stats");
+    ss[0] = buf[0].ssB;
+    if (dual) {
+      Rb.other(launch_rms_stats(x + off1 * kT5Model, nb[1] * L, kT5Model, buf[1].hT, buf[1].ssB, h->bf16, Rb.st), "rms_stats");
+      ss[1] = buf[1].ssB;
+    }
+  }
   for (int l = 0; l < kT5Layers; ++l) {
-    t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
-    if (dual) t5_layer(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl);
+    if (fused) {
+      ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts);
+      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts);
+      parts = kT5Model / 64;
+    } else {
+      t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
+      if (dual) t5_layer(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl);
+    }
     if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
   }
   R.ln(x, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[0] * L, kT5Model, out32, outT);
@@ -883,6 +957,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else if (k == "dual_stream") h->dual_stream = (int)value;
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
+  else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
 }
