@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -931,10 +932,13 @@ int64_t vima_required_params(const VimaConfig* cfg, char* buf, int64_t buflen) {
   std::string out;
   size_t pos = 0;
   const std::string tag = "missing key: ";
+  std::set<std::string> seen;
   while ((pos = msg.find(tag, pos)) != std::string::npos) {
     pos += tag.size();
     size_t end = msg.find('\n', pos);
-    out += msg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+    const std::string key = msg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+    if (!seen.insert(key).second) continue;   // a key the packer reads twice (e.g. a norm weight folded into a GEMM weight)
+    out += key;
     out.push_back('\0');
   }
   if (buf && buflen >= (int64_t)out.size()) memcpy(buf, out.data(), out.size());
