@@ -216,6 +216,26 @@ def main():
     sync()
     warm_ms = (time.perf_counter() - t0) / args.steps * 1e3
 
+    # ---- INCREMENTAL episode: 4 env steps through vima_decode_step (history in the native episode
+    # caches), each step = obs ViT of ONE step + decoder on the newest tokens + action head; reported as an extra
+    obs1 = syn.to_device(syn.make_obs(1, B, args.qv, seed=1536 + rank), dev)
+    act1 = syn.to_device(syn.make_actions(1, B, seed=1636 + rank), dev)
+
+    def episode(n):
+        for t in range(n):
+            otok, omask = pol.forward_obs_token(obs1)
+            atok = pol.forward_action_token(act1) if t > 0 else None
+            pred = pol.forward_step(otok, omask, atok, ptok_c, pmask_c, t)
+            lg = pol.action_logits(pred)
+        return lg
+
+    episode(2)
+    sync()
+    t0 = time.perf_counter()
+    episode(4)
+    sync()
+    inc_ms = (time.perf_counter() - t0) / 4 * 1e3
+
     # ---- per-class kernel time (HIP events on the launch stream), same workload, outside the timed region. The
     # two-stream software pipelining is switched off for this pass so that kernels do not overlap each other and the
     # event-bracketed durations are those of the kernels alone (what rocprofv3 --kernel-trace reports for the
@@ -262,7 +282,8 @@ def main():
                        "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}",
                        "samples_per_s": round(world * B * args.steps / dt, 1),
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),
-                       "warm_ms_per_step": round(warm_ms, 3), "warm_steps_per_s": round(world * 1e3 / warm_ms, 2)},
+                       "warm_ms_per_step": round(warm_ms, 3), "warm_steps_per_s": round(world * 1e3 / warm_ms, 2),
+                       "incremental_env_step_ms": round(inc_ms, 3)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

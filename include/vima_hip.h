@@ -100,6 +100,17 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
                 int Q, int L_act, const float* prompt, int64_t stride_b, int64_t stride_l,
                 const uint8_t* prompt_mask, int Lp, int kv_cache_mode, float* out, vima_stream_t stream);
 
+/* Incremental form of vima_decode for the env-step loop of an episode (scripts/example.py:135-190 re-feeds the whole
+ * history every step): call with step = 0, 1, 2, ... and only the NEWEST tokens -- obs_tok f32
+ * [B,Q,E] / obs_mask u8 [B,Q] of env step `step` and, for step > 0, act_tok f32 [B,E] = the embedded action of step-1.
+ * The handle keeps the per-layer prompt K/V (built at step 0, so `prompt` must be valid there) and the self-attention
+ * K/V, key mask and position counters of the history. out f32 [B,E] = the predicted action token of this step, equal
+ * (up to floating-point reassociation) to row `step` of vima_decode on the full history. step 0 starts a new
+ * episode; any other step must follow step-1 with the same B, Q, Lp. */
+int vima_decode_step(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int step, int B,
+                     int Q, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask,
+                     int Lp, float* out, vima_stream_t stream);
+
 /* VIMAPolicy.forward_action_decoder (vima_policy.py:264-265 -> action_decoder.py:51-52,165-166): tokens f32 [R,E]
  * -> raw logits f32 [R,700] = concat over keys (pose0_position, pose0_rotation, pose1_position, pose1_rotation) of
  * the 12 MLP outputs; the MultiCategorical wrapper (dists.py) stays on the host side. */

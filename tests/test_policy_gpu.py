@@ -166,6 +166,36 @@ def test_prompt_kv_cache_is_exact_and_invalidates():
     assert torch.equal(pol.forward(otok, omask, atok, ptok2, pmask), a)
 
 
+@pytest.mark.parametrize("prec,cfgname,T", [("fp32", "4M", 4), ("bf16", "4M", 4), ("bf16", "20M", 9)])
+def test_incremental_decoding_matches_full_history(prec, cfgname, T):
+    """env-step-by-env-step decoding against the episode caches (vima_decode_step) reproduces the
+    reference-style forward over the re-fed history, including masked observation tokens (position ids skip them) and
+    a padded prompt. T = 9 reaches 80 cached keys (split-key MFMA kernel with a causal offset)."""
+    cfg = syn.config(cfgname)
+    sd = syn.make_state_dict(cfg, 11)
+    pol = loaded_policy(cfg, sd, prec)
+    g = torch.Generator().manual_seed(5)
+    B, Lp, Q, E = 3, 24, 8, cfg.embed_dim
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = torch.ones(B, Lp, dtype=torch.bool)
+    pmask[1, 17:] = False
+    otok = torch.randn(T, B, Q, E, generator=g).to(DEV)
+    omask = torch.rand(T, B, Q, generator=g) > 0.25
+    omask[:, :, 0] = True
+    atok = torch.randn(T - 1, B, E, generator=g).to(DEV)
+    full = pol.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV))
+    tol = 2e-5 if prec == "fp32" else 4e-2
+    for rep in range(2):                                       # a second episode reuses the allocated state
+        for t in range(T):
+            step = pol.forward_step(otok[t], omask[t], atok[t - 1] if t > 0 else None, ptok, pmask, t)
+            assert step.shape == (B, E)
+            assert max_rel(step, full[t]) < tol, (prec, t, max_rel(step, full[t]))
+    with pytest.raises(RuntimeError):                          # step 5 does not follow the last completed step
+        pol.forward_step(otok[0], omask[0], atok[0], ptok, pmask, T + 3)
+    # the history-re-feeding path still works afterwards (and rebuilds its prompt cache)
+    assert max_rel(pol.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV)), full) < 1e-6
+
+
 def test_errors_mirror_reference():
     cfg = syn.config("2M")
     sd = syn.make_state_dict(cfg, 0)

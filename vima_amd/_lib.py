@@ -39,6 +39,8 @@ PROTOTYPES = {
     "vima_t5_encode": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "vima_decode": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    vp, c_i64, c_i64, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "vima_decode_step": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, c_i64, c_i64, vp,
+                                        ctypes.c_int, vp, vp]),
     "vima_action_head": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
     "vima_action_embed": (ctypes.c_int, [vp, vp * 4, ctypes.c_int, vp, vp]),
     "vima_op_linear": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

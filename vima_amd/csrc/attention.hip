@@ -155,6 +155,8 @@ struct AttnDev {
   int B, H, Lq, Lk;
   float scale;
   int mode;
+  int Lkr;      // K / V / mask rows per sample in memory (>= Lk)
+  int q_off;    // causal: query i sits at global position i + q_off
 };
 
 __device__ __forceinline__ float score_fixup(float dot, int mode, float scale, int i, int j, int Lk, bool masked,
@@ -189,15 +191,15 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
   const float* rb = p.relbias ? p.relbias + (long long)h * (2 * p.Lk - 1) : nullptr;
   float mx = -INFINITY;
   for (int j = lane; j < p.Lk; j += 64) {
-    const T* kp = reinterpret_cast<const T*>(p.k) + ((long long)b * p.Lk + j) * p.ldk + h * D;
+    const T* kp = reinterpret_cast<const T*>(p.k) + ((long long)b * p.Lkr + j) * p.ldk + h * D;
     float d = 0.f;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
       const float4 v = load4(kp + c);
       d = fmaf(q[c], v.x, d); d = fmaf(q[c + 1], v.y, d); d = fmaf(q[c + 2], v.z, d); d = fmaf(q[c + 3], v.w, d);
     }
-    const bool masked = p.kmask && !p.kmask[(long long)b * p.Lk + j];
-    const float s = score_fixup(d, p.mode, p.scale, i, j, p.Lk, masked, rb);
+    const bool masked = p.kmask && !p.kmask[(long long)b * p.Lkr + j];
+    const float s = score_fixup(d, p.mode, p.scale, i + p.q_off, j, p.Lk, masked, rb);
     sc[j] = s;
     mx = fmaxf(mx, s);
   }
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
   __syncthreads();
   if (lane < D) {
     float acc = 0.f;
-    const T* vp = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lk * p.ldv + h * D + lane;
+    const T* vp = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lkr * p.ldv + h * D + lane;
     for (int j = 0; j < p.Lk; ++j) acc = fmaf(sc[j], Elem<T>::load(vp + (long long)j * p.ldv), acc);
     T* op = reinterpret_cast<T*>(p.out) + ((long long)b * p.Lq + i) * p.ldo + h * D + lane;
     Elem<T>::store(op, acc / l);
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
     for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float* rb = (MODE == ATTN_T5) ? p.relbias + (long long)h * (2 * p.Lk - 1) + (p.Lk - 1) - qi : nullptr;
-  const uint8_t* km = p.kmask ? p.kmask + (long long)b * p.Lk : nullptr;
+  const uint8_t* km = p.kmask ? p.kmask + (long long)b * p.Lkr : nullptr;
 
   for (int k0 = 0; k0 < p.Lk; k0 += 32) {
     // ---- S^T tile: rows = 32 keys, cols = 32 queries
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     {
       const int krow = (k0 + l31) < p.Lk ? (k0 + l31) : p.Lk - 1;
-      const bf16_t* kp = K + ((long long)b * p.Lk + krow) * p.ldk + h * D + hi * 8;
+      const bf16_t* kp = K + ((long long)b * p.Lkr + krow) * p.ldk + h * D + hi * 8;
 #pragma unroll
       for (int dd = 0; dd < KD; ++dd) {
         const uint4 u = *reinterpret_cast<const uint4*>(kp + dd * 16);
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
       const int c = lane + c0 * 64;
       const int key = c / (D / 8), dc = c % (D / 8);
       const int vrow = (k0 + key) < p.Lk ? (k0 + key) : p.Lk - 1;
-      const uint4 u = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lk + vrow) * p.ldv + h * D + dc * 8);
+      const uint4 u = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lkr + vrow) * p.ldv + h * D + dc * 8);
       const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
           v = s[r] * p.scale + madd;
         } else {
           v = s[r] * p.scale;
-          if (key > qi) v = -1e4f;
+          if (key > qi + p.q_off) v = -1e4f;
           v = v + madd;
         }
       } else {
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
   const int boff = qpad - 1;                                   // index = key - qi + boff in [0, qpad + kpad - 2]
   for (int j = tid; j < kpad; j += 256) {
     float v = -INFINITY;
-    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lk + j]) ? -FLT_MAX : 0.0f;
+    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lkr + j]) ? -FLT_MAX : 0.0f;
     madd[j] = v;
   }
   if (MODE == ATTN_T5) {
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
     const int key = id / CPR, c = id % CPR;
     int row = t * 64 + key;
     row = row < p.Lk ? row : p.Lk - 1;
-    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lk + row) * ld + h * D + c * 8);
+    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lkr + row) * ld + h * D + c * 8);
   };
   auto gload = [&](int t) {
     kreg0 = *gaddr(t, 0, K, p.ldk);
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
           float v;
           if (MODE == ATTN_T5) v = __builtin_fmaf(sv, csc, bq[kl + e]);
           else if (MODE == ATTN_CROSS) v = sv * csc;
-          else v = (k0 + kl + 4 * hi + e > qi) ? -1e4f * kLog2e : sv * csc;
+          else v = (k0 + kl + 4 * hi + e > qi + p.q_off) ? -1e4f * kLog2e : sv * csc;
           x[sub][4 * g + e] = v;
         }
       }
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
 
   for (int j = tid; j < nt * SPLIT_TK; j += 256) {
     float v = -INFINITY;
-    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lk + j]) ? -FLT_MAX : 0.0f;
+    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lkr + j]) ? -FLT_MAX : 0.0f;
     madd[j] = v;
   }
   const int qrow = qi < p.Lq ? qi : p.Lq - 1;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
     const int key = id / CPR, c = id % CPR;
     int row = t * SPLIT_TK + key;
     row = row < p.Lk ? row : p.Lk - 1;
-    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lk + row) * ld + h * D + c * 8);
+    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lkr + row) * ld + h * D + c * 8);
   };
   auto gload = [&](int t) {
     kreg0 = *gaddr(t, 0, K, p.ldk); vreg0 = *gaddr(t, 0, V, p.ldv);
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = s[4 * g + e] * csc;
-          if (MODE == ATTN_CAUSAL && key + e > qi) v = -1e4f * kLog2e;
+          if (MODE == ATTN_CAUSAL && key + e > qi + p.q_off) v = -1e4f * kLog2e;
           v = v + mav[e];
           x[4 * g + e] = v;
           mt = fmaxf(mt, v);
@@ -836,6 +838,8 @@ inline AttnDev to_dev(const AttnArgs& a) {
   d.q = a.q; d.ldq = a.ldq; d.k = a.k; d.ldk = a.ldk; d.v = a.v; d.ldv = a.ldv; d.out = a.out; d.ldo = a.ldo;
   d.kmask = a.kmask; d.relbias = a.relbias; d.B = a.B; d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk; d.scale = a.scale;
   d.mode = a.mode;
+  d.Lkr = a.Lk_rows > 0 ? a.Lk_rows : a.Lk;
+  d.q_off = a.q_off;
   return d;
 }
 

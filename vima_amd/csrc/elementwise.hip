@@ -283,6 +283,45 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict_
   }
 }
 
+// Incremental form of dec_embed_kernel for ONE env step: the newest tokens of every sample ([a_{t-1},] o_t^1 .. o_t^Q) get
+// position ids that continue the sample's running count of valid tokens (cumsum(mask) - 1 over the whole history,
+// xattn_gpt.py:96-103), the count and the history key mask are updated in the episode state.
+template <typename T>
+__global__ __launch_bounds__(256) void dec_embed_step_kernel(const float* __restrict__ obs_tok,
+                                                              const uint8_t* __restrict__ obs_mask,
+                                                              const float* __restrict__ act_tok,
+                                                              const float* __restrict__ pos_table, int n_pos, float* x32,
+                                                              T* xT, uint8_t* hist_mask, int* poscnt, int L_hist, int Lmax,
+                                                              int Q, int has_act, int E) {
+  __shared__ int pos_s[64];
+  const int b = blockIdx.x;
+  const int Ln = Q + has_act;
+  if (threadIdx.x == 0) {
+    int run = poscnt[b];
+    for (int i = 0; i < Ln; ++i) {
+      const int mk = (has_act && i == 0) ? 1 : (obs_mask[(long long)b * Q + (i - has_act)] ? 1 : 0);
+      run += mk;
+      int p = run - 1;
+      p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+      pos_s[i] = p;
+      hist_mask[(long long)b * Lmax + L_hist + i] = (uint8_t)mk;
+    }
+    poscnt[b] = run;
+  }
+  __syncthreads();
+  const int e4 = E >> 2;
+  for (int i = threadIdx.x; i < Ln * e4; i += 256) {
+    const int l = i / e4, c = (i % e4) * 4;
+    const float* src = (has_act && l == 0) ? act_tok + (long long)b * E : obs_tok + ((long long)b * Q + (l - has_act)) * E;
+    const float4 a = *reinterpret_cast<const float4*>(src + c);
+    const float4 pp = *reinterpret_cast<const float4*>(pos_table + (long long)pos_s[l] * E + c);
+    const float4 o = make_float4(a.x + pp.x, a.y + pp.y, a.z + pp.z, a.w + pp.w);
+    const long long off = ((long long)b * Ln + l) * E + c;
+    store4(x32 + off, o);
+    if (xT) store4(xT + off, o);
+  }
+}
+
 // prompt + xattn_positions_embed[cumsum(prompt_mask) - 1]  (vima_policy.py:147, xattn_gpt.py:110-114) -> T [B, Lp, E]
 template <typename T>
 __global__ __launch_bounds__(256) void prompt_pos_kernel(const float* __restrict__ prompt, long long sb, long long sl,
@@ -463,6 +502,20 @@ int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float*
   else
     hipLaunchKernelGGL(dec_embed_kernel<float>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
                        x32, (float*)xT, mask, T, B, Q, L_act, E);
+  return (int)hipGetLastError();
+}
+
+int launch_dec_embed_step(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table, int n_pos,
+                          float* x32, void* xT, uint8_t* hist_mask, int* poscnt, int L_hist, int Lmax, int B, int Q,
+                          int has_act, int E, bool is_bf16, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (Q + has_act > 64 || E % 4 || L_hist + Q + has_act > Lmax) return (int)hipErrorInvalidValue;
+  if (is_bf16)
+    hipLaunchKernelGGL(dec_embed_step_kernel<bf16_t>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
+                       x32, (bf16_t*)xT, hist_mask, poscnt, L_hist, Lmax, Q, has_act, E);
+  else
+    hipLaunchKernelGGL(dec_embed_step_kernel<float>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
+                       x32, (float*)xT, hist_mask, poscnt, L_hist, Lmax, Q, has_act, E);
   return (int)hipGetLastError();
 }
 

@@ -80,6 +80,11 @@ int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const 
 int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table,
                      int n_pos, float* x32, void* xT, uint8_t* mask, int T, int B, int Q, int L_act, int E,
                      bool is_bf16, hipStream_t st);
+// one env step of incremental decoding: newest tokens ([prev action,] Q observation tokens) of every sample -> x32 / xT
+// [B, Q+has_act, E]; position ids continue poscnt[b]; hist_mask[b][L_hist + i] and poscnt[b] are updated
+int launch_dec_embed_step(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table, int n_pos,
+                          float* x32, void* xT, uint8_t* hist_mask, int* poscnt, int L_hist, int Lmax, int B, int Q,
+                          int has_act, int E, bool is_bf16, hipStream_t st);
 // prompt + xattn_positions_embed[cumsum(mask)-1] -> T [B*Lp, E]; input strides in elements (seq-first views ok)
 int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uint8_t* mask, const float* pos_table,
                       int n_pos, void* outT, int B, int Lp, int E, bool is_bf16, hipStream_t st);
@@ -103,6 +108,11 @@ struct AttnArgs {
   int B = 0, H = 0, Lq = 0, Lk = 0, D = 0;
   float scale = 1.0f;
   int mode = ATTN_CROSS;
+  // incremental decoding (keys / values / key mask live in an episode cache with room for Lk_rows >= Lk rows per sample,
+  // the queries are the newest tokens): K/V row = b * Lk_rows + j, mask = kmask[b * Lk_rows + j] (0 -> Lk), and the causal
+  // rule compares key j with the query's GLOBAL position i + q_off.
+  int Lk_rows = 0;
+  int q_off = 0;
 };
 // generic exact kernel (any T); the MFMA flash kernel (bf16, D in {32,64})
 int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st);

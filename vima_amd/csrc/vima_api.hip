@@ -140,6 +140,11 @@ struct VimaHandle {
   size_t kv_cache_bytes = 0;
   int kv_B = 0, kv_Lp = 0;
   bool kv_valid = false;
+  // incremental decoding (vima_decode_step): per-layer self-attention K/V of the history [NL][B][ep_Lmax][2E] (operand
+  // type), its key mask [B][ep_Lmax] and the per-sample count of valid tokens (next position id)
+  void* ep_kv = nullptr; size_t ep_kv_bytes = 0;
+  uint8_t* ep_mask = nullptr; int* ep_poscnt = nullptr; size_t ep_aux_cap = 0;
+  int ep_B = 0, ep_Q = 0, ep_Lmax = 0, ep_Lp = 0, ep_step = -1;
   std::map<std::string, HostParam> host;       // staged until finalize
   std::vector<void*> owned;                     // device allocations of packed weights
   Arena arena;
@@ -887,6 +892,9 @@ void vima_destroy(VimaHandle* h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->ev_layer) (void)hipEventDestroy(e);
   if (h->kv_cache) (void)hipFree(h->kv_cache);
+  if (h->ep_kv) (void)hipFree(h->ep_kv);
+  if (h->ep_mask) (void)hipFree(h->ep_mask);
+  if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -1064,15 +1072,44 @@ int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, cons
   return R.linear(yT, 768, h->t5_post, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
 }
 
-int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
-                int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
-                int kv_cache_mode, float* out, vima_stream_t stream) {
+// Shared body of vima_decode (step < 0: the whole history is re-fed, like the reference) and vima_decode_step (step >= 0:
+// only the newest tokens of env step `step` are processed against the episode's cached self-attention K/V).
+static int decode_impl(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
+                       int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
+                       int kv_cache_mode, float* out, vima_stream_t stream, int step) {
   if (int e = check_ready(h)) return e;
   const int E = h->cfg.embed_dim;
+  const bool inc = step >= 0;
   if (T <= 0 || B <= 0 || Q <= 0) return fail("vima_decode: empty input");
-  if (L_act < 0 || L_act > T || (L_act > 0 && !act_tok) || L_act < T - 1) return fail("vima_decode: L_act must be T-1 or T");
-  const int Lq = T * Q + L_act;
-  if (Lq > h->cfg.n_positions) return fail("vima_decode: history longer than n_positions", 34);
+  if (!inc && (L_act < 0 || L_act > T || (L_act > 0 && !act_tok) || L_act < T - 1)) return fail("vima_decode: L_act must be T-1 or T");
+  const int has_act = inc && step > 0 ? 1 : 0;
+  const int L_hist = inc && step > 0 ? step * (Q + 1) - 1 : 0;     // tokens already in the episode cache
+  const int Lq = inc ? Q + has_act : T * Q + L_act;                // tokens processed by this call, per sample
+  const int Lmax = h->cfg.n_positions;
+  if (L_hist + Lq > h->cfg.n_positions) return fail("vima_decode: history longer than n_positions", 34);
+  if (inc) {
+    if (has_act && !act_tok) return fail("vima_decode_step: the previous action token is required for step > 0");
+    if (step > 0 && !(h->ep_step == step - 1 && h->ep_B == B && h->ep_Q == Q && h->ep_Lp == Lp && h->kv_valid))
+      return fail("vima_decode_step: step " + std::to_string(step) + " does not continue the episode state (last step " +
+                  std::to_string(h->ep_step) + "); start an episode with step 0");
+    kv_cache_mode = step == 0 ? 1 : 2;
+    if (step == 0) {
+      const size_t need = (size_t)h->cfg.xf_n_layers * B * Lmax * 2 * E * h->esz();
+      if (h->ep_kv_bytes < need || h->ep_aux_cap < (size_t)B * Lmax) {
+        HIPCK(hipDeviceSynchronize());
+        if (h->ep_kv) (void)hipFree(h->ep_kv);
+        if (h->ep_mask) (void)hipFree(h->ep_mask);
+        if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
+        h->ep_kv = nullptr; h->ep_mask = nullptr; h->ep_poscnt = nullptr; h->ep_kv_bytes = 0; h->ep_aux_cap = 0;
+        HIPCK(hipMalloc(&h->ep_kv, need));
+        HIPCK(hipMalloc((void**)&h->ep_mask, (size_t)B * Lmax));
+        HIPCK(hipMalloc((void**)&h->ep_poscnt, (size_t)B * sizeof(int)));
+        h->ep_kv_bytes = need; h->ep_aux_cap = (size_t)B * Lmax;
+      }
+      h->ep_step = -1;
+      HIPCK(hipMemsetAsync(h->ep_poscnt, 0, (size_t)B * sizeof(int), (hipStream_t)stream));
+    }
+  }
   if (Lp > h->cfg.xattn_n_positions)   // xattn_gpt.py:110 assert
     return fail("AssertionError: prompt_tokens.size(1) <= xattn_n_positions (" + std::to_string(Lp) + " > " +
                 std::to_string(h->cfg.xattn_n_positions) + ")", 33);
@@ -1100,6 +1137,9 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
     if (h->kv_cache_bytes < kv_layer_bytes * NL) {
       HIPCK(hipDeviceSynchronize());
       if (h->kv_cache) (void)hipFree(h->kv_cache);
+  if (h->ep_kv) (void)hipFree(h->ep_kv);
+  if (h->ep_mask) (void)hipFree(h->ep_mask);
+  if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
       h->kv_cache = nullptr; h->kv_cache_bytes = 0;
       HIPCK(hipMalloc(&h->kv_cache, kv_layer_bytes * NL));
       h->kv_cache_bytes = kv_layer_bytes * NL;
@@ -1122,8 +1162,12 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
   float* n32 = R.ws<float>((size_t)rq * E);
   void* nT = R.wsT((size_t)rq * E);
   if (R.err) return R.err;
-  OTHER(R, launch_dec_embed(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, dmask, T, B, Q, L_act, E,
-                            h->bf16, R.st), "dec_embed");
+  if (inc)
+    OTHER(R, launch_dec_embed_step(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, h->ep_mask, h->ep_poscnt,
+                                   L_hist, Lmax, B, Q, has_act, E, h->bf16, R.st), "dec_embed_step");
+  else
+    OTHER(R, launch_dec_embed(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, dmask, T, B, Q, L_act, E,
+                              h->bf16, R.st), "dec_embed");
   if (build_kv)
     OTHER(R, launch_prompt_pos(prompt, stride_b, stride_l, prompt_mask, h->xpos_emb, h->cfg.xattn_n_positions, pT, B, Lp, E,
                                h->bf16, R.st), "prompt_pos");
@@ -1161,11 +1205,29 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
     R.linear(qn, E, D.l1, rq, ACT_GELU, g, 4 * E, nullptr, 0, nullptr, 0, u, 4 * E);
     R.linear(u, 4 * E, D.l2, rq, ACT_NONE, nullptr, 0, a32, E, x32, E, xT, E);
     // ---- Block.forward (components.py:23-37), post-LN
-    R.linear(xT, E, D.c_attn, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * E);
     AttnArgs s;
-    s.q = qkv; s.ldq = 3 * E; s.k = R.offT(qkv, E); s.ldk = 3 * E; s.v = R.offT(qkv, 2 * E); s.ldv = 3 * E; s.out = ctx; s.ldo = E;
-    s.kmask = dmask; s.B = B; s.H = Hs; s.Lq = Lq; s.Lk = Lq; s.D = E / Hs;
+    s.out = ctx; s.ldo = E; s.B = B; s.H = Hs; s.Lq = Lq; s.D = E / Hs;
     s.scale = 1.0f / sqrtf((float)(E / Hs)); s.mode = ATTN_CAUSAL;
+    if (inc) {
+      // q of the new tokens; their k / v rows are APPENDED to the layer's episode cache by the GEMM's row-remap epilogue
+      // (row b*Lq + i -> b*Lmax + L_hist + i); the new queries attend to history + themselves with a causal offset
+      void* cache = reinterpret_cast<char*>(h->ep_kv) + (size_t)i * B * Lmax * 2 * E * h->esz();
+      GemmArgs gq;
+      gq.A = xT; gq.lda = E; gq.W = D.c_attn.W; gq.ldw = E; gq.M = rq; gq.N = E; gq.K = E; gq.bias = D.c_attn.b;
+      gq.outT = qkv; gq.ldT = E;
+      R.gemm(gq);
+      GemmArgs gk;
+      gk.A = xT; gk.lda = E; gk.W = R.offT(D.c_attn.W, (long long)E * E); gk.ldw = E; gk.M = rq; gk.N = 2 * E; gk.K = E;
+      gk.bias = D.c_attn.b ? D.c_attn.b + E : nullptr;
+      gk.outT = cache; gk.ldT = 2 * E; gk.rb = Lq; gk.s_hi = Lmax; gk.s_lo = 1; gk.ro = L_hist;
+      R.gemm(gk);
+      s.q = qkv; s.ldq = E; s.k = cache; s.ldk = 2 * E; s.v = R.offT(cache, E); s.ldv = 2 * E;
+      s.kmask = h->ep_mask; s.Lk = L_hist + Lq; s.Lk_rows = Lmax; s.q_off = L_hist;
+    } else {
+      R.linear(xT, E, D.c_attn, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * E);
+      s.q = qkv; s.ldq = 3 * E; s.k = R.offT(qkv, E); s.ldk = 3 * E; s.v = R.offT(qkv, 2 * E); s.ldv = 3 * E;
+      s.kmask = dmask; s.Lk = Lq;
+    }
     R.attn(s, h->attn_impl);
     R.linear(ctx, E, D.c_proj, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, nullptr, 0);   // x + a
     R.ln(a32, E, D.ln1_g, D.ln1_b, 1e-5f, 0, rq, E, n32, nT);                           // n = ln_1(x + a)
@@ -1175,11 +1237,29 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
     R.ln(a32, E, D.ln2_g, D.ln2_b, 1e-5f, 0, rq, E, x32, xT);                           // h = ln_2(n + m)
     if (R.err) return R.err;
   }
-  OTHER(R, launch_gather_pred(x32, out, T, B, Q, Lq, E, R.st), "gather_pred");
+  if (inc) OTHER(R, launch_gather_pred(x32, out, 1, B, Lq, Lq, E, R.st), "gather_pred");   // the last new token of every sample
+  else OTHER(R, launch_gather_pred(x32, out, T, B, Q, Lq, E, R.st), "gather_pred");
   if (dual && join_aux(R)) return 1;
   if (kv_cache_mode == 1 && !R.err) { h->kv_valid = true; h->kv_B = B; h->kv_Lp = Lp; }
+  if (inc && !R.err) { h->ep_step = step; h->ep_B = B; h->ep_Q = Q; h->ep_Lp = Lp; h->ep_Lmax = Lmax; }
+  if (!inc) h->ep_step = -1;   // a full-history call may rebuild the prompt cache: the episode state no longer matches
   return R.err;
 }
+
+int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
+                int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
+                int kv_cache_mode, float* out, vima_stream_t stream) {
+  return decode_impl(h, obs_tok, obs_mask, act_tok, T, B, Q, L_act, prompt, stride_b, stride_l, prompt_mask, Lp, kv_cache_mode,
+                     out, stream, -1);
+}
+
+int vima_decode_step(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int step, int B, int Q,
+                     const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp, float* out,
+                     vima_stream_t stream) {
+  if (step < 0) return fail("vima_decode_step: step must be >= 0");
+  return decode_impl(h, obs_tok, obs_mask, act_tok, 1, B, Q, 0, prompt, stride_b, stride_l, prompt_mask, Lp, 0, out, stream, step);
+}
+
 
 int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logits, vima_stream_t stream) {
   if (int e = check_ready(h)) return e;

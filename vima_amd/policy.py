@@ -332,6 +332,38 @@ class VIMAPolicy(nn.Module):
             self._kv_keepalive = (prompt_token, prompt_token_mask)   # the key is only meaningful while these are alive
         return out
 
+    def forward_step(self, obs_token: torch.Tensor, obs_mask: torch.Tensor, prev_action_token: torch.Tensor | None,
+                     prompt_token: torch.Tensor, prompt_token_mask: torch.Tensor, step: int):
+        """Incremental decoding for the env-step loop (no reference counterpart: scripts/example.py re-feeds the whole
+        history to `forward` every step). Pass only the tokens of env step `step`: obs_token [B,Q,E] (or [1,B,Q,E]),
+        obs_mask [B,Q] and, for step > 0, the embedded action of the previous step [B,E] (or [1,B,E]). step 0 starts
+        an episode (prompt K/V and history caches live in the native handle). Returns the predicted action token
+        [B,E] of this step == forward(<full history>)[step]."""
+        self._ready()
+        dev = self._device
+        if obs_token.dim() == 4:
+            obs_token, obs_mask = obs_token[-1], obs_mask[-1]
+        B, Q, E = obs_token.shape
+        obs_token = obs_token.to(device=dev, dtype=torch.float32).contiguous()
+        obs_mask = obs_mask.to(device=dev, dtype=torch.bool).contiguous()
+        if step == 0:
+            assert torch.all(obs_mask[:, 0]), "first observation token of every sample must be valid (position id >= 0)"
+        if prev_action_token is not None:
+            if prev_action_token.dim() == 3:
+                prev_action_token = prev_action_token[-1]
+            prev_action_token = prev_action_token.to(device=dev, dtype=torch.float32).contiguous()
+        if prompt_token.stride(-1) != 1:
+            prompt_token = prompt_token.contiguous()
+        prompt_token = prompt_token.to(dev)
+        prompt_token_mask = prompt_token_mask.to(device=dev, dtype=torch.bool).contiguous()
+        Lp = prompt_token.shape[0]
+        out = torch.empty(B, E, dtype=torch.float32, device=dev)
+        self._kv_key = None   # the native prompt cache now belongs to this episode
+        _lib.check(self._lib.vima_decode_step(
+            self._handle, _ptr(obs_token), _ptr(obs_mask), _ptr(prev_action_token), int(step), B, Q, _ptr(prompt_token),
+            prompt_token.stride(1), prompt_token.stride(0), _ptr(prompt_token_mask), Lp, _ptr(out), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ actions
     def action_logits(self, predicted_action_tokens: torch.Tensor) -> torch.Tensor:
         """Raw concatenated logits [..., 700] of the 12 action-head MLPs (input of MultiCategoricalHead,
