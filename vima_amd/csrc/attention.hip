@@ -396,7 +396,7 @@ __device__ __forceinline__ int kswz(int r, int c) {
 }
 
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void attn_mfma4_kernel(const AttnDev p) {
+__global__ __launch_bounds__(256, D == 32 ? 4 : 3) void attn_mfma4_kernel(const AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
   constexpr int KD = D / 16, OT = D / 32, CPR = D / 8;       // k-steps, O^T tiles, 16-B chunks per K/V row
   constexpr int ROWB = D * 2;

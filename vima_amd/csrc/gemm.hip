@@ -503,8 +503,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (outT) store4(outT + orow * p.ldT + n, v);
             sq = sumsq4(v);
           }
-          if (p.ssq_out) {   // wave-uniform; the LPR lanes of a row are consecutive: butterfly, one partial per row
-            static_assert(WCOLS == 64, "RMS partial sums are per 64 output columns");
+          if (WCOLS == 64 && p.ssq_out) {   // wave-uniform; the LPR lanes of a row are consecutive: butterfly, one partial per row
 #pragma unroll
             for (int o = 1; o < LPR; o <<= 1) sq += __shfl_xor(sq, o, 64);
             if ((lane % LPR) == 0 && m < p.M && n < p.N) p.ssq_out[(long long)m * (p.N >> 6) + ((n0 + wn * WCOLS) >> 6)] = sq;
