@@ -120,6 +120,25 @@ def test_linear_large_tile(M, N, K, tile, persist):
         pol.set_option("gemm_persist", 1)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode,B,H,Lq,Lk,D", [(1, 2, 16, 9, 40, 16), (2, 2, 2, 17, 17, 128), (1, 1, 2, 8, 70, 128), (2, 3, 16, 30, 30, 16)])
+def test_attention_other_head_dims(prec, mode, B, H, Lq, Lk, D):
+    """Head dims 16 and 128 (the head counts are free parameters) run on the exact generic kernel."""
+    pol = bare_policy(prec)
+    g = torch.Generator().manual_seed(D + Lq)
+    q, k, v = (torch.randn(B, L, H, D, generator=g) for L in (Lq, Lk, Lk))
+    kmask = torch.rand(B, Lk, generator=g) > 0.2
+    kmask[:, 0] = True
+    scale = 1.0 / math.sqrt(D)
+    ref = attn_ref(bf(q), bf(k), bf(v), kmask, None, scale, mode) if prec == "bf16" else attn_ref(q, k, v, kmask, None, scale, mode)
+    out = torch.full((B, Lq, H, D), float("nan"), device="cuda")
+    qd, kd, vd, md = q.cuda(), k.cuda(), v.cuda(), kmask.cuda()
+    _lib.check(pol._lib.vima_op_attention(pol._handle, ptr(qd), ptr(kd), ptr(vd), ptr(md), None, B, H, Lq, Lk, D, scale, mode, 0,
+                                          ptr(out), pol._stream()))
+    torch.cuda.synchronize()
+    assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)
+
+
 def test_linear_transpose_detecting():
     """A = I with an asymmetric W: output must equal W^T exactly (catches swapped C-layout / operand order)."""
     pol = bare_policy("fp32")

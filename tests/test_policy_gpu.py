@@ -196,6 +196,28 @@ def test_incremental_decoding_matches_full_history(prec, cfgname, T):
     assert max_rel(pol.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV)), full) < 1e-6
 
 
+@pytest.mark.parametrize("heads", [16, 2])
+def test_other_head_counts_against_oracle(heads):
+    """embed_dim 256 with 16 heads (head dim 16) and 2 heads (head dim 128): the head counts are free parameters of
+    the checkpoint config; these sizes take the exact generic attention kernel in both precisions."""
+    cfg = syn.PolicyConfig(256, 2, heads, heads)
+    sd = syn.make_state_dict(cfg, 21)
+    orc = OraclePolicy(sd, **cfg.ctor_kwargs())
+    g = torch.Generator().manual_seed(heads)
+    B, Lp, Q, T, E = 2, 20, 4, 2, cfg.embed_dim
+    ptok = torch.randn(Lp, B, E, generator=g)
+    pmask = torch.ones(B, Lp, dtype=torch.bool)
+    pmask[1, 15:] = False
+    otok = torch.randn(T, B, Q, E, generator=g)
+    omask = torch.ones(T, B, Q, dtype=torch.bool)
+    atok = torch.randn(T - 1, B, E, generator=g)
+    ref = orc.forward(otok, omask, atok, ptok, pmask)
+    for prec, tol in (("fp32", 2e-5), ("bf16", 4e-2)):
+        pol = loaded_policy(cfg, sd, prec)
+        got = pol.forward(otok.to(DEV), omask.to(DEV), atok.to(DEV), ptok.to(DEV), pmask.to(DEV))
+        assert max_rel(got, ref) < tol, (prec, max_rel(got, ref))
+
+
 def test_errors_mirror_reference():
     cfg = syn.config("2M")
     sd = syn.make_state_dict(cfg, 0)

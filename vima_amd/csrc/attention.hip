@@ -212,11 +212,11 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
   }
   l = wave_sum(l);
   __syncthreads();
-  if (lane < D) {
+  for (int dl = lane; dl < D; dl += 64) {   // D = 128: two output columns per lane
     float acc = 0.f;
-    const T* vp = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lkr * p.ldv + h * D + lane;
+    const T* vp = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lkr * p.ldv + h * D + dl;
     for (int j = 0; j < p.Lk; ++j) acc = fmaf(sc[j], Elem<T>::load(vp + (long long)j * p.ldv), acc);
-    T* op = reinterpret_cast<T*>(p.out) + ((long long)b * p.Lq + i) * p.ldo + h * D + lane;
+    T* op = reinterpret_cast<T*>(p.out) + ((long long)b * p.Lq + i) * p.ldo + h * D + dl;
     Elem<T>::store(op, acc / l);
   }
 }
@@ -872,22 +872,28 @@ int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, 
   return (int)hipGetLastError();
 }
 
-int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
-  if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
-  if (a.D != 32 && a.D != 64) return (int)hipErrorInvalidValue;
-  if (a.mode == ATTN_T5 && !a.relbias) return (int)hipErrorInvalidValue;
-  const AttnDev d = to_dev(a);
+template <typename T>
+static int launch_generic_t(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   dim3 grid((unsigned)a.Lq, (unsigned)a.H, (unsigned)a.B);
   const size_t sh = (size_t)a.Lk * sizeof(float);
-  if (is_bf16) {
-    if (a.D == 32) hipLaunchKernelGGL((attn_generic_kernel<bf16_t, 32>), grid, dim3(64), sh, st, d);
-    else hipLaunchKernelGGL((attn_generic_kernel<bf16_t, 64>), grid, dim3(64), sh, st, d);
-  } else {
-    if (a.D == 32) hipLaunchKernelGGL((attn_generic_kernel<float, 32>), grid, dim3(64), sh, st, d);
-    else hipLaunchKernelGGL((attn_generic_kernel<float, 64>), grid, dim3(64), sh, st, d);
+  switch (a.D) {
+    case 16: hipLaunchKernelGGL((attn_generic_kernel<T, 16>), grid, dim3(64), sh, st, d); break;
+    case 32: hipLaunchKernelGGL((attn_generic_kernel<T, 32>), grid, dim3(64), sh, st, d); break;
+    case 64: hipLaunchKernelGGL((attn_generic_kernel<T, 64>), grid, dim3(64), sh, st, d); break;
+    case 128: hipLaunchKernelGGL((attn_generic_kernel<T, 128>), grid, dim3(64), sh, st, d); break;
+    default: return (int)hipErrorInvalidValue;
   }
   return (int)hipGetLastError();
 }
+
+// head dims 16 / 32 / 64 / 128 (the MFMA flash kernels cover 32 and 64; the others run here)
+int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
+  if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
+  if (a.mode == ATTN_T5 && !a.relbias) return (int)hipErrorInvalidValue;
+  const AttnDev d = to_dev(a);
+  return is_bf16 ? launch_generic_t<bf16_t>(d, a, st) : launch_generic_t<float>(d, a, st);
+}
+
 
 int g_attn4_min_lq = 64;   // queries per (batch, head) from which the 4-wave LDS-shared kernel is used
 void set_attn4_min_lq(int v) { g_attn4_min_lq = v; }

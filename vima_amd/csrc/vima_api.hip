@@ -540,7 +540,7 @@ struct Run {
     if (err) return err;
     prof_begin(1, 4.0 * a.B * (double)a.H * a.Lq * (double)a.Lk * a.D);
     int e;
-    if (impl == 1 && h->bf16) e = launch_attn_mfma(a, st);
+    if (impl == 1 && h->bf16 && (a.D == 32 || a.D == 64)) e = launch_attn_mfma(a, st);   // other head dims: exact generic kernel
     else e = launch_attn_generic(a, h->bf16, st);
     prof_end();
     if (e) err = fail(std::string("attention launch failed: ") + hipGetErrorString((hipError_t)e), e);
@@ -859,8 +859,9 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   if (E % cfg->sattn_n_heads || E % cfg->xattn_n_heads)   // components.py:120-123 raises ValueError
     return fail("dim (" + std::to_string(E) + ") must be divisible by num_heads", 22);
   const int ds = E / cfg->sattn_n_heads, dx = E / cfg->xattn_n_heads;
-  if ((ds != 32 && ds != 64) || (dx != 32 && dx != 64))
-    return fail("vima_create: head dim must be 32 or 64 (got " + std::to_string(ds) + "/" + std::to_string(dx) + ")");
+  auto head_ok = [](int d) { return d == 16 || d == 32 || d == 64 || d == 128; };   // 32 / 64: MFMA flash kernels
+  if (!head_ok(ds) || !head_ok(dx))
+    return fail("vima_create: head dim must be 16, 32, 64 or 128 (got " + std::to_string(ds) + "/" + std::to_string(dx) + ")");
   if (E % 64 || E > 1024) return fail("vima_create: embed_dim must be a multiple of 64 and <= 1024");
   if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16) return fail("vima_create: bad precision");
   if (cfg->n_positions <= 0 || cfg->n_positions > 512 || cfg->xattn_n_positions <= 0) return fail("vima_create: bad table sizes");
