@@ -22,15 +22,6 @@ def main():
     pol.set_option("gemm_raster", int(os.environ.get("RASTER", "0")))
     pol.set_option("gemm_epi", int(os.environ.get("EPI", "1")))
     pol.set_option("op_bf16_out", int(os.environ.get("BF16OUT", "0")))   # 1: bf16-only output like most in-model GEMMs
-    pad = int(os.environ.get("PAD", "0"))      # padded row strides (timing experiment, wrong results)
-    M0, N0 = M, N
-    if pad:
-        os.environ["VIMA_GEMM_DEBUG_LD"] = str(K + pad)
-        os.environ["VIMA_GEMM_DEBUG_M"] = str(M)
-        os.environ["VIMA_GEMM_DEBUG_N"] = str(N)
-        M = (M * (K + pad) + K - 1) // K
-        N = (N * (K + pad) + K - 1) // K
-        N = (N + 3) // 4 * 4
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * 0.03
     out = torch.empty(M, N, device="cuda")
@@ -77,9 +68,8 @@ def main():
               f"{key.unique().numel()} distinct CUs, gap between consecutive workgroups of a CU mean {g.mean():.2f} us "
               f"(median {g.median():.2f}, p95 {g.quantile(0.95):.2f}); CU busy fraction {sum(busy) / len(busy):.3f}; "
               f"span {(rt1.max() - rt0.min()) / 100.0:.1f} us")
-    M, N = M0, N0
     ms = pr["ms"] / max(pr["launches"], 1)
-    print(f"M{M} N{N} K{K} pad{pad} tile{tile} raster{os.environ.get('RASTER', '0')} epi{os.environ.get('EPI', '1')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    print(f"M{M} N{N} K{K} tile{tile} raster{os.environ.get('RASTER', '0')} epi{os.environ.get('EPI', '1')}: {ms:.3f} ms = {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

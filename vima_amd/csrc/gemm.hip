@@ -1025,16 +1025,6 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     return (int)hipErrorInvalidValue;
   GemmDev d;
   d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
-  {   // experiment only (wrong results): override the row strides of A and W (0 = every row aliases row 0)
-    static int dbg = -2;
-    if (dbg == -2) dbg = env_int("VIMA_GEMM_DEBUG_LD", -1);
-    if (dbg >= 0) {   // the caller allocates M' x K, N' x K with M' K >= M ld: the kernel then runs the M x N problem
-      d.lda = dbg; d.ldw = dbg;
-      const int m = env_int("VIMA_GEMM_DEBUG_M", 0), n = env_int("VIMA_GEMM_DEBUG_N", 0);
-      if (m > 0) d.M = m;
-      if (n > 0) d.N = n;
-    }
-  }
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
