@@ -33,6 +33,20 @@ def main():
     for _ in range(iters):
         _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 1, p(out), pol._stream()))
     torch.cuda.synchronize()
+    if os.environ.get("STAMPS"):
+        nwg = B * H * ((Lq + 127) // 128) + 64
+        dbg = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+        pol.set_option("attn_dbg_ptr", dbg.data_ptr())
+        _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 1, p(out), pol._stream()))
+        torch.cuda.synchronize()
+        pol.set_option("attn_dbg_ptr", 0)
+        d = dbg.view(-1, 8).cpu().double()
+        d = d[d[:, 1] > 0][:, :6]
+        nt = (L + 63) // 64
+        names = ["issue global loads", "S^T (K frags + MFMA)", "softmax", "PV (V frags + MFMA)", "LDS store of next tile", "barrier"]
+        tot = d.sum(1).mean()
+        print("  wave-0 shader clocks per key tile (%d workgroups, %d tiles each): " % (d.shape[0], nt) +
+              ", ".join(f"{n} {d[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; total {tot / nt:.0f}")
     pr = pol.prof_read()["attention"]
     ms = pr["ms"] / max(pr["launches"], 1)
     print(f"attn mode{mode} B{B} H{H} Lq{Lq} Lk{L} D{D}: {ms:.3f} ms = {4.0 * B * H * Lq * L * D / ms / 1e9:.1f} TFLOP/s")

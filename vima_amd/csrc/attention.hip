@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
 }
 
 // =============================================================================================== generic exact kernel
+long long* g_attn_dbg = nullptr;
+
 struct AttnDev {
   const void* q; int ldq;
   const void* k; int ldk;
@@ -157,6 +159,7 @@ struct AttnDev {
   int mode;
   int Lkr;      // K / V / mask rows per sample in memory (>= Lk)
   int q_off;    // causal: query i sits at global position i + q_off
+  long long* dbg;   // optional (4-wave kernel): per workgroup 8 accumulated shader-clock phase totals of wave 0
 };
 
 __device__ __forceinline__ float score_fixup(float dot, int mode, float scale, int i, int j, int Lk, bool masked,
@@ -479,19 +482,23 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
   // staging registers of the next tile (named scalars, not arrays: hipcc kept `uint4 kreg[CH]` in scratch memory, which
   // forced a vmcnt(0) + scratch round trip right behind every global load and exposed its full latency every tile)
   uint4 kreg0, kreg1, vreg0, vreg1;
-  auto gaddr = [&](int t, int i, const bf16_t* base, int ld) {
-    const int id = tid + i * 256;
-    const int key = id / CPR, c = id % CPR;
-    int row = t * 64 + key;
-    row = row < p.Lk ? row : p.Lk - 1;
-    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lkr + row) * ld + h * D + c * 8);
-  };
+  // running per-thread pointers to this thread's chunk(s) of the CURRENT tile; a tile step is 64 rows. Only a ragged last
+  // tile needs the row clamp (64-bit multiplies per load otherwise cost ~15 % of the loop in address arithmetic).
+  const int key0 = tid / CPR, ch0 = tid % CPR;
+  const int key1 = (tid + 256) / CPR, ch1 = (tid + 256) % CPR;
+  const bf16_t* Kb = K + (long long)b * p.Lkr * p.ldk + h * D;
+  const bf16_t* Vb = V + (long long)b * p.Lkr * p.ldv + h * D;
   auto gload = [&](int t) {
-    kreg0 = *gaddr(t, 0, K, p.ldk);
-    vreg0 = *gaddr(t, 0, V, p.ldv);
+    int r0 = t * 64 + key0, r1 = t * 64 + key1;
+    if ((t + 1) * 64 > p.Lk) {   // workgroup-uniform: ragged last tile
+      r0 = r0 < p.Lk ? r0 : p.Lk - 1;
+      r1 = r1 < p.Lk ? r1 : p.Lk - 1;
+    }
+    kreg0 = *reinterpret_cast<const uint4*>(Kb + (long long)r0 * p.ldk + ch0 * 8);
+    vreg0 = *reinterpret_cast<const uint4*>(Vb + (long long)r0 * p.ldv + ch0 * 8);
     if constexpr (CH > 1) {
-      kreg1 = *gaddr(t, 1, K, p.ldk);
-      vreg1 = *gaddr(t, 1, V, p.ldv);
+      kreg1 = *reinterpret_cast<const uint4*>(Kb + (long long)r1 * p.ldk + ch1 * 8);
+      vreg1 = *reinterpret_cast<const uint4*>(Vb + (long long)r1 * p.ldv + ch1 * 8);
     }
   };
   auto lstore1 = [&](int buf, int i, const uint4& kr, const uint4& vr) {
@@ -510,10 +517,16 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
   gload(0);
   lstore(0);
   __syncthreads();
+  long long ph[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() { return (long long)__builtin_readcyclecounter(); };
+  const bool dbg = p.dbg != nullptr;
+  long long t_prev = dbg ? now() : 0;
+  auto mark = [&](int i) { if (dbg) { const long long t = now(); ph[i] += t - t_prev; t_prev = t; } };
 
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) gload(t + 1);                              // in flight while this tile is multiplied
+    mark(0);   // global loads of the next tile issued
     const char* ks = ks_base + buf * KS_BYTES;
     const char* vt = vt_base + buf * VT_BYTES + vlane;
     const int k0 = t * 64;
@@ -530,6 +543,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[dd], s[sub], 0, 0, 0);
       }
     }
+    mark(1);   // S^T MFMAs issued
     // ---- scores -> probabilities (fp32), in the LOG2 domain: x' = log2(e) * (scaled score + bias) is ONE fma per element
     // (the bias table is pre-multiplied), p = exp2(x' - m'). The additive key mask (0 / -finfo.max / -inf) is added
     // unscaled: it absorbs x' exactly as it absorbs x in the reference, so fully masked rows still come out uniform.
@@ -594,6 +608,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
       }
     rs += __shfl_xor(rs, 32, 64);
     l_run += rs;
+    mark(2);   // softmax
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -613,8 +628,15 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
           ot[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vu), pf, ot[it], 0, 0, 0);
         }
       }
+    mark(3);   // PV MFMAs issued
     if (t + 1 < nt) lstore(buf ^ 1);
+    mark(4);   // next tile written to LDS (waits for its global loads)
     if (!(VIMA_ATTN_ABLATE & 1)) __syncthreads();
+    mark(5);   // barrier
+  }
+  if (dbg && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.dbg[(long long)blockIdx.x * 8 + i] = ph[i];
   }
   if (qi < p.Lq) {
     const float inv = 1.0f / l_run;
@@ -847,6 +869,7 @@ inline AttnDev to_dev(const AttnArgs& a) {
   d.mode = a.mode;
   d.Lkr = a.Lk_rows > 0 ? a.Lk_rows : a.Lk;
   d.q_off = a.q_off;
+  d.dbg = g_attn_dbg;
   return d;
 }
 
@@ -897,6 +920,7 @@ int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
 
 int g_attn4_min_lq = 64;   // queries per (batch, head) from which the 4-wave LDS-shared kernel is used
 void set_attn4_min_lq(int v) { g_attn4_min_lq = v; }
+void set_attn_dbg(long long* p) { g_attn_dbg = p; }
 
 template <int D, int MODE>
 static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {

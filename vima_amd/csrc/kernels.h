@@ -118,6 +118,7 @@ struct AttnArgs {
 int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st);
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st);
 void set_attn_split(int v);     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
+void set_attn_dbg(long long* p);  // debug: device buffer [workgroups*8] of accumulated phase clocks of the 4-wave kernel (nullptr = off)
 void set_attn4_min_lq(int v);   // Lq threshold for the 4-wave LDS-shared flash kernel (below: 1-wave kernel)
 
 }  // namespace vima

@@ -965,6 +965,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_persist") set_gemm_persist((int)value);
   else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
+  else if (k == "attn_dbg_ptr") set_attn_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn_split") set_attn_split((int)value);
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
