@@ -149,6 +149,11 @@ int vima_prof_enable(VimaHandle* h, int on);
 int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], double out_flops[3]);
 /* bytes currently held by the workspace arena */
 int64_t vima_workspace_bytes(VimaHandle* h);
+/* hipGraph replay (vima_set_option(h, "graphs", 1)): the per-env-step entry points (vima_obs_encode, vima_decode,
+ * vima_decode_step, vima_action_head, vima_action_embed) capture their launch sequence the second time the same call
+ * (shapes, pointers, options) is seen and replay it afterwards -- at small batch a step is ~1300 microsecond kernels and
+ * the host launch rate is the bound. Results are bit-identical to eager execution. Counts since handle creation. */
+int vima_graph_stats(VimaHandle* h, int64_t* replays, int64_t* captures);
 
 #ifdef __cplusplus
 }

@@ -218,6 +218,42 @@ def test_other_head_counts_against_oracle(heads):
         assert max_rel(got, ref) < tol, (prec, max_rel(got, ref))
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_graph_replay_is_exact(prec):
+    """hipGraph replay of the per-env-step entry points (option "graphs"): the same warm loop and the same incremental
+    episode, eager vs captured + replayed, must give bit-identical results; replays must actually happen."""
+    cfg = syn.config("4M")
+    sd = syn.make_state_dict(cfg, 7)
+    g = torch.Generator().manual_seed(3)
+    B, Lp, Q, E, T = 2, 24, 8, cfg.embed_dim, 4
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = torch.ones(B, Lp, dtype=torch.bool, device=DEV)
+    obs = syn.to_device(syn.make_obs(1, B, Q // 2, seed=5), DEV)
+    acts = syn.to_device(syn.make_actions(1, B, seed=6), DEV)
+
+    def loop(pol):
+        outs = []
+        for rep in range(4):                                  # identical calls: eager, capture, replay, replay
+            otok, omask = pol.forward_obs_token(obs)
+            pred = pol.forward(otok, omask, None, ptok, pmask)
+            outs.append(pol.action_logits(pred[-1]).clone())
+        for rep in range(3):                                  # three identical episodes through the incremental path
+            for t in range(T):
+                otok, omask = pol.forward_obs_token(obs)
+                atok = pol.forward_action_token(acts) if t > 0 else None
+                outs.append(pol.action_logits(pol.forward_step(otok, omask, atok, ptok, pmask, t)).clone())
+        torch.cuda.synchronize()
+        return outs
+
+    eager = loop(loaded_policy(cfg, sd, prec))
+    polg = loaded_policy(cfg, sd, prec, graphs=1)
+    graphed = loop(polg)
+    replays, captures = polg.graph_stats()
+    assert captures > 0 and replays > captures, (replays, captures)
+    for a, b in zip(eager, graphed):
+        assert torch.equal(a, b)
+
+
 def test_errors_mirror_reference():
     cfg = syn.config("2M")
     sd = syn.make_state_dict(cfg, 0)

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "vima_prof_read": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
                                       ctypes.POINTER(ctypes.c_double)]),
     "vima_workspace_bytes": (c_i64, [vp]),
+    "vima_graph_stats": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
 }
 
 _lib = None

@@ -10,6 +10,7 @@
 
 #include <map>
 #include <set>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,7 @@ struct Arena {          // stream-ordered bump allocator; chunks are only releas
   std::vector<Chunk> chunks;
   size_t used = 0;      // in the last chunk
   size_t total_need = 0;
+  uint64_t gen = 0;     // bumped whenever a chunk is allocated or freed (addresses baked into captured graphs go stale)
   int reset() {
     if (chunks.size() > 1) {   // consolidate so steady state is a single allocation
       size_t tot = 0;
@@ -83,6 +85,7 @@ struct Arena {          // stream-ordered bump allocator; chunks are only releas
       if (hipDeviceSynchronize() != hipSuccess) return 1;
       for (auto& c : chunks) (void)hipFree(c.p);
       chunks.clear();
+      ++gen;
       char* p = nullptr;
       if (hipMalloc((void**)&p, tot) != hipSuccess) return 1;
       chunks.push_back({p, tot});
@@ -98,6 +101,7 @@ struct Arena {          // stream-ordered bump allocator; chunks are only releas
       char* p = nullptr;
       if (hipMalloc((void**)&p, cap) != hipSuccess) return nullptr;
       chunks.push_back({p, cap});
+      ++gen;
       used = 0;
     }
     void* r = chunks.back().p + used;
@@ -145,6 +149,18 @@ struct VimaHandle {
   void* ep_kv = nullptr; size_t ep_kv_bytes = 0;
   uint8_t* ep_mask = nullptr; int* ep_poscnt = nullptr; size_t ep_aux_cap = 0;
   int ep_B = 0, ep_Q = 0, ep_Lmax = 0, ep_Lp = 0, ep_step = -1;
+  // hipGraph replay of the per-env-step entry points (option "graphs"): at small batch a step is ~1300 launches of
+  // microsecond kernels and the HOST launch rate is the bound. The launch sequence of a call is captured the second time
+  // the same (entry point, shapes, pointers, options, workspace generation) is seen and replayed afterwards.
+  int graph_mode = 0;
+  uint64_t state_gen = 0;       // bumped when options / cache allocations change what a captured graph bakes in
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_gin = nullptr, ev_gout = nullptr;
+  struct GraphEntry { hipGraphExec_t exec; uint64_t last_use; };
+  std::unordered_map<std::string, GraphEntry> graphs;
+  std::unordered_map<std::string, int> graph_seen;   // eager runs so far; -1: capture failed, stay eager
+  uint64_t graph_clock = 0;
+  int64_t graph_replays = 0, graph_captures = 0;
   std::map<std::string, HostParam> host;       // staged until finalize
   std::vector<void*> owned;                     // device allocations of packed weights
   Arena arena;
@@ -842,6 +858,87 @@ int check_ready(VimaHandle* h) {
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------- hipGraph replay
+void drop_graphs(VimaHandle* h) {
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+  h->graphs.clear();
+  h->graph_seen.clear();
+}
+
+std::string gkey(const char* name, std::initializer_list<long long> vals) {
+  std::string k = name;
+  char buf[24];
+  for (long long v : vals) {
+    snprintf(buf, sizeof buf, ":%llx", (unsigned long long)v);
+    k += buf;
+  }
+  return k;
+}
+
+// Runs fn(stream) -- the pure launch sequence of one entry point -- eagerly, or, in graph mode, as a captured and cached
+// hipGraph on the handle's internal stream (ordered after / before the caller's stream by events; the caller's stream may
+// be the legacy NULL stream, which cannot be captured). A key is captured the second time it is seen: the first, eager,
+// run sizes the workspace, creates events and sets the kernels' function attributes. Anything that fails during a
+// capture (e.g. the workspace had to grow) makes that key permanently eager.
+template <typename F>
+int run_graphed(VimaHandle* h, std::string key, hipStream_t user, F&& fn) {
+  if (!h->graph_mode || h->prof) return fn(user);
+  HIPCK(hipSetDevice(h->device));
+  if (!h->gstream) {
+    HIPCK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming));
+  }
+  HIPCK(hipEventRecord(h->ev_gin, user));
+  HIPCK(hipStreamWaitEvent(h->gstream, h->ev_gin, 0));
+  key += gkey("", {(long long)h->state_gen, (long long)h->arena.gen, h->bf16 ? 1 : 0});
+  int rc = 0;
+  auto it = h->graphs.find(key);
+  if (it != h->graphs.end()) {
+    it->second.last_use = ++h->graph_clock;
+    ++h->graph_replays;
+    if (hipGraphLaunch(it->second.exec, h->gstream) != hipSuccess) rc = fail("hipGraphLaunch failed");
+  } else {
+    int& seen = h->graph_seen[key];
+    if (seen < 1) {
+      if (seen == 0) seen = 1;
+      rc = fn(h->gstream);
+    } else if (hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      (void)hipGetLastError();
+      seen = -1;
+      rc = fn(h->gstream);
+    } else {
+      const uint64_t gen0 = h->arena.gen;
+      const int e = fn(h->gstream);
+      hipGraph_t g = nullptr;
+      const hipError_t ec = hipStreamEndCapture(h->gstream, &g);
+      hipGraphExec_t exec = nullptr;
+      if (!e && ec == hipSuccess && g && h->arena.gen == gen0 &&
+          hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess) {
+        if (h->graphs.size() >= 96) {   // evict the least recently used executable
+          auto lru = h->graphs.begin();
+          for (auto j = h->graphs.begin(); j != h->graphs.end(); ++j)
+            if (j->second.last_use < lru->second.last_use) lru = j;
+          (void)hipGraphExecDestroy(lru->second.exec);
+          h->graphs.erase(lru);
+        }
+        h->graphs[key] = {exec, ++h->graph_clock};
+        ++h->graph_captures;
+        if (hipGraphLaunch(exec, h->gstream) != hipSuccess) rc = fail("hipGraphLaunch failed");
+      } else {
+        (void)hipGetLastError();
+        seen = -1;
+        rc = e ? e : fn(h->gstream);   // nothing ran during the failed capture
+      }
+      if (g) (void)hipGraphDestroy(g);
+    }
+  }
+  HIPCK(hipEventRecord(h->ev_gout, h->gstream));
+  HIPCK(hipStreamWaitEvent(user, h->ev_gout, 0));
+  return rc;
+}
+
 }  // namespace
 
 // =================================================================================================== C ABI
@@ -896,6 +993,10 @@ void vima_destroy(VimaHandle* h) {
   if (h->ep_kv) (void)hipFree(h->ep_kv);
   if (h->ep_mask) (void)hipFree(h->ep_mask);
   if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
+  drop_graphs(h);
+  if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
+  if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
+  if (h->gstream) (void)hipStreamDestroy(h->gstream);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -957,7 +1058,14 @@ int64_t vima_required_params(const VimaConfig* cfg, char* buf, int64_t buflen) {
 int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   if (!h || !key) return fail("vima_set_option: null argument");
   const std::string k = key;
-  if (k == "attn_impl") h->attn_impl = (int)value;
+  ++h->state_gen;   // any option may change what a captured launch sequence contains
+  if (!h->graphs.empty()) {
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipDeviceSynchronize());
+  }
+  drop_graphs(h);
+  if (k == "graphs") h->graph_mode = (int)value;
+  else if (k == "attn_impl") h->attn_impl = (int)value;
   else if (k == "gemm_variant") set_gemm_variant((int)value);
   else if (k == "gemm_tile") set_gemm_tile((int)value);
   else if (k == "gemm_raster") set_gemm_raster((int)value);
@@ -1002,6 +1110,13 @@ int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], dou
 
 int64_t vima_workspace_bytes(VimaHandle* h) { return h ? (int64_t)h->arena.bytes() : 0; }
 
+int vima_graph_stats(VimaHandle* h, int64_t* replays, int64_t* captures) {
+  if (!h || !replays || !captures) return fail("vima_graph_stats: null argument");
+  *replays = h->graph_replays;
+  *captures = h->graph_captures;
+  return 0;
+}
+
 int vima_obj_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2], int n, int qv, float* out,
                     vima_stream_t stream) {
   if (int e = check_ready(h)) return e;
@@ -1014,19 +1129,25 @@ int vima_obj_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t*
 int vima_obs_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2],
                     const uint8_t* const mask[2], const int64_t* ee, int n, int qv, float* out_tokens, uint8_t* out_mask,
                     vima_stream_t stream) {
-  if (int e = check_ready(h)) return e;
-  Run R{h, (hipStream_t)stream};
-  const int E = h->cfg.embed_dim;
-  const int rows = n * 2 * qv;
-  if (rows == 0) return 0;
-  void* featT = R.wsT((size_t)rows * E);
-  if (R.err) return R.err;
-  if (obj_encode(R, crops, bbox, n, qv, nullptr, featT)) return R.err;
-  // obs_fusion_layer on cat(img_feats, ee_feats) (vima_policy.py:253-256)
-  R.linear(featT, E, h->fuse, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
-  OTHER(R, launch_add_row_table(out_tokens, rows, E, h->ee_table, (const long long*)ee, 2 * qv, R.st), "ee_table");
-  concat_mask(R, mask, n, qv, out_mask);
-  return R.err;
+  if (!h) return fail("null handle");
+  const std::string key = gkey("obs_encode", {(long long)(uintptr_t)crops[0], (long long)(uintptr_t)crops[1], (long long)(uintptr_t)bbox[0],
+                                              (long long)(uintptr_t)bbox[1], (long long)(uintptr_t)mask[0], (long long)(uintptr_t)mask[1],
+                                              (long long)(uintptr_t)ee, n, qv, (long long)(uintptr_t)out_tokens, (long long)(uintptr_t)out_mask});
+  return run_graphed(h, key, (hipStream_t)stream, [&](hipStream_t st) -> int {
+    if (int e = check_ready(h)) return e;
+    Run R{h, st};
+    const int E = h->cfg.embed_dim;
+    const int rows = n * 2 * qv;
+    if (rows == 0) return 0;
+    void* featT = R.wsT((size_t)rows * E);
+    if (R.err) return R.err;
+    if (obj_encode(R, crops, bbox, n, qv, nullptr, featT)) return R.err;
+    // obs_fusion_layer on cat(img_feats, ee_feats) (vima_policy.py:253-256)
+    R.linear(featT, E, h->fuse, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
+    OTHER(R, launch_add_row_table(out_tokens, rows, E, h->ee_table, (const long long*)ee, 2 * qv, R.st), "ee_table");
+    concat_mask(R, mask, n, qv, out_mask);
+    return R.err;
+  });
 }
 
 int vima_t5_encode(VimaHandle* h, const float* x, const uint8_t* mask, int B, int L, float* out, vima_stream_t stream) {
@@ -1074,12 +1195,17 @@ int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, cons
   return R.linear(yT, 768, h->t5_post, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
 }
 
-// Shared body of vima_decode (step < 0: the whole history is re-fed, like the reference) and vima_decode_step (step >= 0:
-// only the newest tokens of env step `step` are processed against the episode's cached self-attention K/V).
-static int decode_impl(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
-                       int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
-                       int kv_cache_mode, float* out, vima_stream_t stream, int step) {
-  if (int e = check_ready(h)) return e;
+// vima_decode (step < 0: the whole history is re-fed, like the reference) and vima_decode_step (step >= 0: only the newest
+// tokens of env step `step` are processed against the episode's cached self-attention K/V) share three stages:
+// decode_prepare (validation, cache (re)allocation, state invalidation -- host only), decode_launch (the pure launch
+// sequence: eager, captured or replayed) and decode_commit (host state after a successful launch).
+struct DecodePlan { bool inc; int has_act, L_hist, Lq, Lmax, kv_mode; };
+
+static int decode_prepare(VimaHandle* h, const float* act_tok, int T, int B, int Q, int L_act, int Lp, int kv_cache_mode, int step,
+                          DecodePlan& P) {
+  if (!h) return fail("null handle");
+  if (!h->finalized) return fail("weights not finalized: call vima_set_param for every key, then vima_finalize_params");
+  HIPCK(hipSetDevice(h->device));
   const int E = h->cfg.embed_dim;
   const bool inc = step >= 0;
   if (T <= 0 || B <= 0 || Q <= 0) return fail("vima_decode: empty input");
@@ -1089,6 +1215,9 @@ static int decode_impl(VimaHandle* h, const float* obs_tok, const uint8_t* obs_m
   const int Lq = inc ? Q + has_act : T * Q + L_act;                // tokens processed by this call, per sample
   const int Lmax = h->cfg.n_positions;
   if (L_hist + Lq > h->cfg.n_positions) return fail("vima_decode: history longer than n_positions", 34);
+  if (Lp > h->cfg.xattn_n_positions)   // xattn_gpt.py:110 assert
+    return fail("AssertionError: prompt_tokens.size(1) <= xattn_n_positions (" + std::to_string(Lp) + " > " +
+                std::to_string(h->cfg.xattn_n_positions) + ")", 33);
   if (inc) {
     if (has_act && !act_tok) return fail("vima_decode_step: the previous action token is required for step > 0");
     if (step > 0 && !(h->ep_step == step - 1 && h->ep_B == B && h->ep_Q == Q && h->ep_Lp == Lp && h->kv_valid))
@@ -1107,14 +1236,44 @@ static int decode_impl(VimaHandle* h, const float* obs_tok, const uint8_t* obs_m
         HIPCK(hipMalloc((void**)&h->ep_mask, (size_t)B * Lmax));
         HIPCK(hipMalloc((void**)&h->ep_poscnt, (size_t)B * sizeof(int)));
         h->ep_kv_bytes = need; h->ep_aux_cap = (size_t)B * Lmax;
+        ++h->state_gen;
       }
       h->ep_step = -1;
-      HIPCK(hipMemsetAsync(h->ep_poscnt, 0, (size_t)B * sizeof(int), (hipStream_t)stream));
     }
   }
-  if (Lp > h->cfg.xattn_n_positions)   // xattn_gpt.py:110 assert
-    return fail("AssertionError: prompt_tokens.size(1) <= xattn_n_positions (" + std::to_string(Lp) + " > " +
-                std::to_string(h->cfg.xattn_n_positions) + ")", 33);
+  if (kv_cache_mode < 0 || kv_cache_mode > 2) return fail("vima_decode: kv_cache_mode must be 0, 1 or 2");
+  if (kv_cache_mode == 2 && !(h->kv_valid && h->kv_B == B && h->kv_Lp == Lp))
+    return fail("vima_decode: kv_cache_mode 2 without a matching cache (build it with mode 1 for the same B, Lp)");
+  if (kv_cache_mode == 1) {
+    const size_t need = (size_t)B * Lp * 2 * E * h->esz() * h->cfg.xf_n_layers;
+    h->kv_valid = false;
+    if (h->kv_cache_bytes < need) {
+      HIPCK(hipDeviceSynchronize());
+      if (h->kv_cache) (void)hipFree(h->kv_cache);
+      h->kv_cache = nullptr; h->kv_cache_bytes = 0;
+      HIPCK(hipMalloc(&h->kv_cache, need));
+      h->kv_cache_bytes = need;
+      ++h->state_gen;
+    }
+  }
+  if (!inc) h->ep_step = -1;   // a full-history call may rebuild the prompt cache: the episode state no longer matches
+  P = DecodePlan{inc, has_act, L_hist, Lq, Lmax, kv_cache_mode};
+  return 0;
+}
+
+static void decode_commit(VimaHandle* h, const DecodePlan& P, int B, int Q, int Lp, int step) {
+  if (P.kv_mode == 1) { h->kv_valid = true; h->kv_B = B; h->kv_Lp = Lp; }
+  if (P.inc) { h->ep_step = step; h->ep_B = B; h->ep_Q = Q; h->ep_Lp = Lp; h->ep_Lmax = P.Lmax; }
+}
+
+static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
+                         int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
+                         const DecodePlan& P, float* out, hipStream_t stream) {
+  if (int e = check_ready(h)) return e;
+  const int E = h->cfg.embed_dim;
+  const bool inc = P.inc;
+  const int has_act = P.has_act, L_hist = P.L_hist, Lq = P.Lq, Lmax = P.Lmax, kv_cache_mode = P.kv_mode;
+  if (inc && L_hist == 0) HIPCK(hipMemsetAsync(h->ep_poscnt, 0, (size_t)B * sizeof(int), stream));
   Run R{h, (hipStream_t)stream};
   const int rq = B * Lq, rp = B * Lp;
   const int Hx = h->cfg.xattn_n_heads, Hs = h->cfg.sattn_n_heads;
@@ -1128,25 +1287,9 @@ static int decode_impl(VimaHandle* h, const float* obs_tok, const uint8_t* obs_m
   // they are all issued on the auxiliary stream up front (one buffer per layer) and overlap the serial decoder chain;
   // with kv_cache_mode 1/2 they live in a handle-owned cache that survives across calls (one episode = one prompt).
   const int NL = h->cfg.xf_n_layers;
-  if (kv_cache_mode < 0 || kv_cache_mode > 2) return fail("vima_decode: kv_cache_mode must be 0, 1 or 2");
   const bool use_cache = kv_cache_mode != 0;
   const bool build_kv = kv_cache_mode != 2;
   const size_t kv_layer_bytes = (size_t)rp * 2 * E * h->esz();
-  if (kv_cache_mode == 2 && !(h->kv_valid && h->kv_B == B && h->kv_Lp == Lp))
-    return fail("vima_decode: kv_cache_mode 2 without a matching cache (build it with mode 1 for the same B, Lp)");
-  if (kv_cache_mode == 1) {
-    h->kv_valid = false;
-    if (h->kv_cache_bytes < kv_layer_bytes * NL) {
-      HIPCK(hipDeviceSynchronize());
-      if (h->kv_cache) (void)hipFree(h->kv_cache);
-  if (h->ep_kv) (void)hipFree(h->ep_kv);
-  if (h->ep_mask) (void)hipFree(h->ep_mask);
-  if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
-      h->kv_cache = nullptr; h->kv_cache_bytes = 0;
-      HIPCK(hipMalloc(&h->kv_cache, kv_layer_bytes * NL));
-      h->kv_cache_bytes = kv_layer_bytes * NL;
-    }
-  }
   const bool dual = h->dual_stream != 0 && build_kv;
   std::vector<void*> KVs(NL);
   if (use_cache) {
@@ -1242,31 +1385,47 @@ static int decode_impl(VimaHandle* h, const float* obs_tok, const uint8_t* obs_m
   if (inc) OTHER(R, launch_gather_pred(x32, out, 1, B, Lq, Lq, E, R.st), "gather_pred");   // the last new token of every sample
   else OTHER(R, launch_gather_pred(x32, out, T, B, Q, Lq, E, R.st), "gather_pred");
   if (dual && join_aux(R)) return 1;
-  if (kv_cache_mode == 1 && !R.err) { h->kv_valid = true; h->kv_B = B; h->kv_Lp = Lp; }
-  if (inc && !R.err) { h->ep_step = step; h->ep_B = B; h->ep_Q = Q; h->ep_Lp = Lp; h->ep_Lmax = Lmax; }
-  if (!inc) h->ep_step = -1;   // a full-history call may rebuild the prompt cache: the episode state no longer matches
   return R.err;
 }
 
 int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int T, int B, int Q,
                 int L_act, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp,
                 int kv_cache_mode, float* out, vima_stream_t stream) {
-  return decode_impl(h, obs_tok, obs_mask, act_tok, T, B, Q, L_act, prompt, stride_b, stride_l, prompt_mask, Lp, kv_cache_mode,
-                     out, stream, -1);
+  DecodePlan P;
+  if (int e = decode_prepare(h, act_tok, T, B, Q, L_act, Lp, kv_cache_mode, -1, P)) return e;
+  const std::string key = gkey("decode", {(long long)(uintptr_t)obs_tok, (long long)(uintptr_t)obs_mask, (long long)(uintptr_t)act_tok, T, B, Q,
+                                          L_act, (long long)(uintptr_t)prompt, stride_b, stride_l, (long long)(uintptr_t)prompt_mask, Lp,
+                                          P.kv_mode, (long long)(uintptr_t)out, (long long)(uintptr_t)h->kv_cache});
+  const int rc = run_graphed(h, key, (hipStream_t)stream, [&](hipStream_t st) {
+    return decode_launch(h, obs_tok, obs_mask, act_tok, T, B, Q, L_act, prompt, stride_b, stride_l, prompt_mask, Lp, P, out, st);
+  });
+  if (!rc) decode_commit(h, P, B, Q, Lp, -1);
+  return rc;
 }
 
 int vima_decode_step(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int step, int B, int Q,
                      const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp, float* out,
                      vima_stream_t stream) {
   if (step < 0) return fail("vima_decode_step: step must be >= 0");
-  return decode_impl(h, obs_tok, obs_mask, act_tok, 1, B, Q, 0, prompt, stride_b, stride_l, prompt_mask, Lp, 0, out, stream, step);
+  DecodePlan P;
+  if (int e = decode_prepare(h, act_tok, 1, B, Q, 0, Lp, 0, step, P)) return e;
+  const std::string key = gkey("decode_step", {(long long)(uintptr_t)obs_tok, (long long)(uintptr_t)obs_mask, (long long)(uintptr_t)act_tok, step,
+                                               B, Q, (long long)(uintptr_t)prompt, stride_b, stride_l, (long long)(uintptr_t)prompt_mask,
+                                               Lp, (long long)(uintptr_t)out, (long long)(uintptr_t)h->kv_cache, (long long)(uintptr_t)h->ep_kv});
+  const int rc = run_graphed(h, key, (hipStream_t)stream, [&](hipStream_t st) {
+    return decode_launch(h, obs_tok, obs_mask, act_tok, 1, B, Q, 0, prompt, stride_b, stride_l, prompt_mask, Lp, P, out, st);
+  });
+  if (!rc) decode_commit(h, P, B, Q, Lp, step);
+  return rc;
 }
 
-
 int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logits, vima_stream_t stream) {
+  if (!h) return fail("null handle");
+  const std::string key = gkey("action_head", {(long long)(uintptr_t)tokens, Rn, (long long)(uintptr_t)out_logits});
+  return run_graphed(h, key, (hipStream_t)stream, [&](hipStream_t st) -> int {
   if (int e = check_ready(h)) return e;
   if (Rn <= 0) return 0;
-  Run R{h, (hipStream_t)stream};
+  Run R{h, st};
   const int E = h->cfg.embed_dim;
   const int HH = kNumHeadsOut * kHeadHidden;
   void* tT = R.wsT((size_t)Rn * E);
@@ -1290,12 +1449,17 @@ int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logi
     col += kHeadBins[j];
   }
   return R.err;
+  });
 }
 
 int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int Rn, float* out, vima_stream_t stream) {
+  if (!h) return fail("null handle");
+  const std::string key = gkey("action_embed", {(long long)(uintptr_t)idx[0], (long long)(uintptr_t)idx[1], (long long)(uintptr_t)idx[2],
+                                                (long long)(uintptr_t)idx[3], Rn, (long long)(uintptr_t)out});
+  return run_graphed(h, key, (hipStream_t)stream, [&](hipStream_t st) -> int {
   if (int e = check_ready(h)) return e;
   if (Rn <= 0) return 0;
-  Run R{h, (hipStream_t)stream};
+  Run R{h, st};
   const int E = h->cfg.embed_dim;
   void* t1 = R.wsT((size_t)Rn * 1024);
   void* t2 = R.wsT((size_t)Rn * 1024);
@@ -1308,6 +1472,7 @@ int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int Rn, float*
   a.bias = h->act1_b; a.bsBias = 256; a.outT = t2; a.ldT = 1024; a.bsT = 256;
   R.gemm(a);
   return R.linear(t2, 1024, h->act_post, Rn, ACT_NONE, nullptr, 0, nullptr, 0, out, E, nullptr, 0);
+  });
 }
 
 // ---------------------------------------------------------------------------------------------- operator-level

@@ -426,6 +426,13 @@ class VIMAPolicy(nn.Module):
         return actions
 
     # ------------------------------------------------------------------ instrumentation
+    def graph_stats(self):
+        """(replays, captures) of the hipGraph replay mode (set_option("graphs", 1))."""
+        self._ready()
+        r, c = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self._lib.vima_graph_stats(self._handle, ctypes.byref(r), ctypes.byref(c)))
+        return int(r.value), int(c.value)
+
     def prof_enable(self, on: bool = True):
         self._ensure_handle()
         _lib.check(self._lib.vima_prof_enable(self._handle, 1 if on else 0))
