@@ -139,6 +139,44 @@ def test_attention_other_head_dims(prec, mode, B, H, Lq, Lk, D):
     assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("M,N,K", [(8, 768, 3072), (77, 520, 1536), (512, 768, 3072), (300, 1300, 2048)])
+def test_linear_split_k(prec, M, N, K):
+    """Opt-in deterministic two-pass split-K (underfilled grids, K >= 1536): every epilogue feature goes through the
+    reduce pass; two runs are bit-identical."""
+    pol = bare_policy(prec)
+    pol.set_option("gemm_splitk", 1)
+    cast = bf if prec == "bf16" else (lambda t: t)
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        for act, use_b, use_m, use_r in [(0, 0, 0, 0), (3, 1, 0, 1), (2, 1, 1, 0), (1, 1, 0, 0)]:
+            A = torch.randn(M, K, generator=g)
+            W = torch.randn(N, K, generator=g) * K ** -0.5
+            b = torch.randn(N, generator=g) if use_b else None
+            m = torch.randn(M, N, generator=g) if use_m else None
+            r = torch.randn(M, N, generator=g) if use_r else None
+            ref = cast(A).double() @ cast(W).double().T
+            if b is not None:
+                ref = ref + b
+            ref = ACTS[act](ref.float())
+            if m is not None:
+                ref = ref * cast(m)
+            if r is not None:
+                ref = ref + r
+            d = [None if t is None else t.cuda() for t in (A, W, b, m, r)]
+            outs = []
+            for _ in range(2):
+                out = torch.full((M, N), float("nan"), device="cuda")
+                _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, act,
+                                                   ptr(out), pol._stream()))
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1])
+            assert max_rel(outs[0], ref) < (2e-3 if prec == "bf16" else 2e-5), (act, use_b, use_m, use_r)
+    finally:
+        pol.set_option("gemm_splitk", 0)
+
+
 def test_linear_transpose_detecting():
     """A = I with an asymmetric W: output must equal W^T exactly (catches swapped C-layout / operand order)."""
     pol = bare_policy("fp32")

@@ -1013,6 +1013,61 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ split-K
+// With M = 8 .. 512 rows (batch 1 .. 32 decoder / prompt GEMMs) a 128x128 grid has 6 .. 100 workgroups, each walking
+// its K dimension serially at the per-CU operand-path rate (~23 B/clk): 8 us at K = 768, 30 us at K = 3072, most CUs
+// idle. Such problems are split along K into S ranges (pass 1: the same kernel, batched over the ranges, raw fp32
+// partials) and finished by an elementwise pass that sums the partials in split order -- deterministic -- and applies
+// the whole epilogue. The summation order differs from the single-pass kernels, i.e. results would depend (at fp32
+// rounding level) on whether a problem was small enough to be split -- batch-composition and chunking invariance would
+// only hold to bf16 tolerance. Measured gain: 35 -> 25 us at M = 8, K = 3072; nothing at K = 768 (a second launch costs
+// as much as the saved slices); batch-1 step 6.2 -> 5.5 ms. It is therefore OPT-IN (option gemm_splitk / VIMA_GEMM_SPLITK).
+int g_gemm_splitk = -1;
+
+struct SplitPlan { int S; int Ks; };
+inline SplitPlan splitk_plan(const GemmArgs& a, bool is_bf16) {
+  SplitPlan p{1, a.K};
+  if (!env_cached("VIMA_GEMM_SPLITK", g_gemm_splitk, 0)) return p;
+  const int bk = is_bf16 ? 64 : 32;
+  if (a.batch > 1 || a.M <= 0 || a.N <= 0 || a.K % bk || a.N % 4 || a.ssq_out || a.rb > 0) return p;
+  const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  const int slices = a.K / bk;
+  if (tiles >= 128 || slices < 24) return p;   // measured: the second pass only pays from K = 1536 (bf16) on
+  const int want = (int)((256 + tiles - 1) / tiles);
+  int best = 1;
+  for (int s = 2; s <= want && s * 2 <= slices; ++s)
+    if (slices % s == 0) best = s;
+  if (best > 1) { p.S = best; p.Ks = slices / best * bk; }
+  return p;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, long long MN, int M, int N,
+                                                          const float* bias, int act, const T* mul, int ldmul,
+                                                          const float* res, int ldres, float* out32, int ld32, T* outT, int ldT,
+                                                          const float* rs_ssq, int rs_parts, float rs_invk, float rs_eps) {
+  const int n4 = N >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+  const float* q = part + (long long)m * N + n;
+  float4 v = load4(q);
+  for (int s = 1; s < S; ++s) {   // fixed order: deterministic
+    const float4 t = load4(q + s * MN);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  if (rs_ssq) {
+    const float r = rms_row_scale(rs_ssq, rs_parts, m, rs_invk, rs_eps);
+    v.x *= r; v.y *= r; v.z *= r; v.w *= r;
+  }
+  if (bias) { const float4 b = load4(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+  if (mul) { const float4 g = load4(mul + (long long)m * ldmul + n); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
+  if (res) { const float4 r4 = load4(res + (long long)m * ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+  if (out32) store4(out32 + (long long)m * ld32 + n, v);
+  if (outT) store4(outT + (long long)m * ldT + n, v);
+}
+
 template <typename T>
 int launch_t(const GemmArgs& a, hipStream_t st) {
   constexpr int BK = 128 / (int)sizeof(T);   // K granularity of the widest K-slice (TileS / TileL)
@@ -1023,6 +1078,24 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (!aligned_to(a.A, 16) || !aligned_to(a.W, 16) || (a.lda * es) % 16 || (a.ldw * es) % 16 ||
       (a.bsA * es) % 16 || (a.bsW * es) % 16)
     return (int)hipErrorInvalidValue;
+  if (a.splitk_ws) {   // underfilled grid: two deterministic passes (see splitk_plan)
+    const SplitPlan sp = splitk_plan(a, sizeof(T) == 2);
+    const long long MN = (long long)a.M * a.N;
+    const bool ok4 = (!a.bias || aligned_to(a.bias, 16)) && (!a.mul || (aligned_to(a.mul, 4 * es) && a.ldmul % 4 == 0)) &&
+                     (!a.res || (aligned_to(a.res, 16) && a.ldres % 4 == 0)) && (!a.out32 || (aligned_to(a.out32, 16) && a.ld32 % 4 == 0)) &&
+                     (!a.outT || (aligned_to(a.outT, 4 * es) && a.ldT % 4 == 0));
+    if (sp.S > 1 && ok4 && a.splitk_ws_bytes >= (size_t)sp.S * MN * sizeof(float) && aligned_to(a.splitk_ws, 16)) {
+      GemmArgs p1;
+      p1.A = a.A; p1.lda = a.lda; p1.W = a.W; p1.ldw = a.ldw; p1.M = a.M; p1.N = a.N; p1.K = sp.Ks;
+      p1.batch = sp.S; p1.bsA = sp.Ks; p1.bsW = sp.Ks; p1.out32 = a.splitk_ws; p1.ld32 = a.N; p1.bs32 = MN;
+      if (int e = launch_t<T>(p1, st)) return e;
+      const long long work = (long long)a.M * (a.N / 4);
+      hipLaunchKernelGGL(gemm_reduce_kernel<T>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a.splitk_ws, sp.S, MN, a.M,
+                         a.N, a.bias, a.act, reinterpret_cast<const T*>(a.mul), a.ldmul, a.res, a.ldres, a.out32, a.ld32,
+                         reinterpret_cast<T*>(a.outT), a.ldT, a.rs_ssq, a.rs_parts, a.rs_invk, a.rs_eps);
+      return (int)hipGetLastError();
+    }
+  }
   GemmDev d;
   d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
@@ -1069,6 +1142,12 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st) {
   return is_bf16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
 }
+size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16) {
+  const SplitPlan sp = splitk_plan(a, is_bf16);
+  return sp.S > 1 ? (size_t)sp.S * a.M * a.N * sizeof(float) : 0;
+}
+void set_gemm_splitk(int v) { g_gemm_splitk = v; }
+int get_gemm_splitk() { return env_cached("VIMA_GEMM_SPLITK", g_gemm_splitk, 0); }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_tile(int v) { g_gemm_tile = v; }
 void set_gemm_raster(int v) { g_gemm_raster = v; }

@@ -37,9 +37,18 @@ struct GemmArgs {
   const float* rs_ssq = nullptr;
   int rs_parts = 0;
   float rs_invk = 0.f, rs_eps = 0.f;
+  // split-K scratch (fp32 [S][M][N] partial products) for grids that would leave most CUs idle; size it with
+  // gemm_splitk_bytes(). Without it the launch is a single pass.
+  float* splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
 };
 // returns hipError_t as int; is_bf16 selects the operand type
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
+// Bytes of split-K scratch this problem wants (0: single pass). Deterministic two-pass split-K: pass 1 = the same GEMM
+// kernel over S K-ranges writing fp32 partials, pass 2 = gemm_reduce_kernel (sum in split order + the full epilogue).
+size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
+void set_gemm_splitk(int v);        // 1 = split-K for underfilled grids with K >= 1536, 0 = never (default: results stay independent of the batch size)
+int get_gemm_splitk();
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin
 void set_gemm_raster(int v);        // tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major

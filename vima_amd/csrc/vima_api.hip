@@ -522,6 +522,11 @@ struct Run {
 
   int gemm(GemmArgs a) {
     if (err) return err;
+    if (const size_t wsb = gemm_splitk_bytes(a, h->bf16)) {   // underfilled grid: scratch for the two-pass split-K
+      a.splitk_ws = ws<float>(wsb / sizeof(float));
+      a.splitk_ws_bytes = wsb;
+      if (err) return err;
+    }
     prof_begin(0, 2.0 * a.M * (double)a.N * a.K * (a.batch > 0 ? a.batch : 1));
     int e = launch_gemm(a, h->bf16, st);
     prof_end();
@@ -818,7 +823,9 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   Run Rb{h, h->aux};
   if (dual && fork_aux(R)) return R.err = 1;
   const long long off1 = (long long)nb[0] * L;      // first row of the second half
-  const bool fused = h->t5_fuse_rms != 0;
+  // with the opt-in split-K, small problems keep the standalone RMSNorm: the producer-side statistics are not available
+  // from the two-pass split-K, and the norm kernels cost microseconds there
+  const bool fused = h->t5_fuse_rms != 0 && (!get_gemm_splitk() || (long long)nb[0] * L >= 8192);
   const float* ss[2] = {nullptr, nullptr};
   int parts = 1;
   if (fused) {   // entry of the chain: operand-type copy of x and its row sums of squares (one partial per row)
@@ -1071,6 +1078,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_raster") set_gemm_raster((int)value);
   else if (k == "gemm_epi") set_gemm_epi((int)value);
   else if (k == "gemm_persist") set_gemm_persist((int)value);
+  else if (k == "gemm_splitk") set_gemm_splitk((int)value);
   else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "attn_dbg_ptr") set_attn_dbg(reinterpret_cast<long long*>((uintptr_t)value));

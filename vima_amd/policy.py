@@ -211,6 +211,18 @@ class VIMAPolicy(nn.Module):
             _pair(mask[0].data_ptr(), mask[1].data_ptr()), _ptr(ee), n, qv, _ptr(out), _ptr(omask), self._stream()))
         return out.view(*lead, 2 * qv, E), omask.view(*lead, 2 * qv)
 
+    def t5_encode(self, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """T5PromptEncoder.forward on already assembled embeddings (prompt_encoder.py:30-58): x [B,L,768] fp32,
+        mask [B,L] bool -> [B,L,768] (before t5_prompt_encoder_post_layer). Sub-module level entry for parity tests."""
+        self._ready()
+        dev = self._device
+        x = x.to(device=dev, dtype=torch.float32).contiguous()
+        mask = mask.to(device=dev, dtype=torch.bool).contiguous()
+        B, L, _ = x.shape
+        out = torch.empty_like(x)
+        _lib.check(self._lib.vima_t5_encode(self._handle, _ptr(x), _ptr(mask), B, L, _ptr(out), self._stream()))
+        return out
+
     def obj_encoder(self, cropped_img, bbox, mask=None):
         """ObjEncoder.forward (obj_encoder.py:66-95) for inputs with ONE leading dim: -> [n, 2*Qv, E]."""
         self._ready()
