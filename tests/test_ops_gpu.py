@@ -45,8 +45,8 @@ def test_linear_epilogues(prec, variant, M, N, K):
         assert max_rel(out, ref) < (2e-3 if prec == "bf16" else 2e-5), (act, use_b, use_m, use_r)
 
 
-@pytest.mark.parametrize("tile", [1, 2])
-@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (1000, 1304, 1536), (77, 520, 128)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 7, 8])
+@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (1000, 1304, 1536), (77, 520, 128), (8, 768, 768), (30, 200, 3072)])
 def test_linear_bf16_output_path(M, N, K, tile):
     """GEMM epilogues that write ONLY the bf16 operand copy (QKV, MLP hidden, K/V projections): 16-byte-store path of the
     LDS-transposed epilogue, with bias / activation / gate multiply / residual."""
@@ -175,6 +175,27 @@ def test_linear_split_k(prec, M, N, K):
             assert max_rel(outs[0], ref) < (2e-3 if prec == "bf16" else 2e-5), (act, use_b, use_m, use_r)
     finally:
         pol.set_option("gemm_splitk", 0)
+
+
+def test_small_tiles_match_128_tile_bitwise():
+    """The 64x64 / 32x64 tiles chosen for underfilled grids accumulate K in the same order as the 128x128 tile: results
+    must be BIT-identical (batch-composition invariance does not depend on the tile choice)."""
+    pol = bare_policy("bf16")
+    g = torch.Generator().manual_seed(9)
+    try:
+        for M, N, K in [(8, 768, 3072), (32, 2304, 768), (200, 768, 768), (500, 3072, 768)]:
+            A, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+            b, r = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+            outs = []
+            for small in (1, 0):
+                pol.set_option("gemm_small", small)
+                out = torch.full((M, N), float("nan"), device="cuda")
+                _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(A), ptr(W), ptr(b), None, ptr(r), M, N, K, 2, ptr(out), pol._stream()))
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (M, N, K)
+    finally:
+        pol.set_option("gemm_small", 1)
 
 
 def test_linear_transpose_detecting():

@@ -66,6 +66,8 @@ struct Tile {
   static constexpr int SMEM_ALLOC = SMEM_BYTES + (PREFETCH ? NW * 256 : 0);
 };
 using TileS = Tile<128, 128, 2, 2, 128, 2>;   // 64 KiB, 2 workgroups / CU
+using Tile64 = Tile<64, 64, 2, 2, 128, 4>;    // 64 KiB ring of four 16-KiB slices, 4 waves of 32x32: underfilled grids (M <= 512 or so)
+using TileXS = Tile<32, 64, 1, 2, 128, 4>;    // 48 KiB ring of four 12-KiB slices, 2 waves of 32x32: M <= 32 (one env step at batch <= 4)
 using TileL = Tile<256, 256, 2, 4, 128, 2>;   // 128 KiB, 1 workgroup / CU, 8 waves
 
 template <int RB> __device__ __forceinline__ int swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
@@ -156,9 +158,12 @@ __device__ __forceinline__ f32x16_t mma(const Frag<float>& w, const Frag<float>&
 __device__ __forceinline__ float rms_row_scale(const float* ssq, int parts, int row, float invk, float eps) {
   const float* q = ssq + (long long)row * parts;
   float t;
-  if (parts == 12) {   // E = 768: three independent 16-byte loads (a scalar loop serialises twelve load latencies)
-    const float4 a = load4(q), b = load4(q + 4), c = load4(q + 8);
-    t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + ((c.x + c.y) + (c.z + c.w));
+  if (parts == 24) {   // E = 768: six independent 16-byte loads (a scalar loop serialises the load latencies); pairs of
+    // 32-column partials are summed first -- the same add every producer shape would do for a 64-column group
+    const float4 a = load4(q), b = load4(q + 4), c = load4(q + 8), d = load4(q + 12), e = load4(q + 16), f = load4(q + 20);
+    const float s0 = a.x + a.y, s1 = a.z + a.w, s2 = b.x + b.y, s3 = b.z + b.w, s4 = c.x + c.y, s5 = c.z + c.w;
+    const float s6 = d.x + d.y, s7 = d.z + d.w, s8 = e.x + e.y, s9 = e.z + e.w, s10 = f.x + f.y, s11 = f.z + f.w;
+    t = (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) + ((s8 + s9) + (s10 + s11));
   } else {
     t = 0.f;
     for (int j = 0; j < parts; ++j) t += q[j];
@@ -503,10 +508,9 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (outT) store4(outT + orow * p.ldT + n, v);
             sq = sumsq4(v);
           }
-          if (WCOLS == 64 && p.ssq_out) {   // wave-uniform; the LPR lanes of a row are consecutive: butterfly, one partial per row
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) sq += __shfl_xor(sq, o, 64);
-            if ((lane % LPR) == 0 && m < p.M && n < p.N) p.ssq_out[(long long)m * (p.N >> 6) + ((n0 + wn * WCOLS) >> 6)] = sq;
+          if (p.ssq_out) {   // wave-uniform; 8 consecutive lanes hold 32 columns of one row: butterfly, one partial per 32 columns
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            if ((lane & 7) == 0 && m < p.M && n < p.N) p.ssq_out[(long long)m * (p.N >> 5) + (n >> 5)] = sq;
           }
         }
       }
@@ -800,7 +804,6 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const float rsc = rscv[mi];
-      float sqrow[4] = {0.f, 0.f, 0.f, 0.f};   // per row (it*8 + lane/8) sum of squares over the wave's 64 columns
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int nbase = n0 + wn * (NI * 32) + ni * 32;
@@ -875,20 +878,11 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
               if (outT) store4(outT + orow * p.ldT + n, v);
               sq = sumsq4(v);
             }
-            if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly in the canonical order
+            if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly, one partial per row and slab
               sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-              sqrow[it] = ni == 0 ? sq : sqrow[it] + sq;   // (columns 0-31) + (columns 32-63): the xor-8 stage of a 16-lane row
+              if ((elane & 7) == 0 && m < p.M && n < p.N) ssq_out[(long long)m * (p.N >> 5) + (nbase >> 5)] = sq;   // plain store: deterministic
             }
           }
-        }
-      }
-      if (ssq_out) {   // one partial per row and 64-column slab (plain store: deterministic)
-        const int mbase = m0 + wm * (MI * 32) + mi * 32;
-        const int nslab = n0 + wn * (NI * 32);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int m = mbase + it * 8 + (elane >> 3);
-          if ((elane & 7) == 0 && m < p.M && nslab < p.N) ssq_out[(long long)m * (p.N >> 6) + (nslab >> 6)] = sqrow[it];
         }
       }
     }
@@ -966,6 +960,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   }
 }
 
+int g_gemm_small = -1;     // 1 (default): 64x64 / 32x64 tiles for underfilled grids; VIMA_GEMM_SMALL / option gemm_small
 int g_gemm_persist = -1;   // 1 (default): large bf16 GEMMs run on the persistent kernel; VIMA_GEMM_PERSIST / option gemm_persist
 int g_num_cu = 0;
 
@@ -1103,7 +1098,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
-  if (a.ssq_out && (!a.out32 || a.batch > 1 || a.N % 64 != 0)) return (int)hipErrorInvalidValue;
+  if (a.ssq_out && (!a.out32 || a.batch > 1 || a.N % 32 != 0)) return (int)hipErrorInvalidValue;
   if (a.rs_ssq && a.rs_parts <= 0) return (int)hipErrorInvalidValue;
   d.mtiles = d.ntiles = 0;
   bool v = (a.N % 4 == 0);
@@ -1123,7 +1118,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 224) && waste < 1.15;
     if (gemm_tile() == 1) large = false;
-    if (gemm_tile() >= 2) large = v;
+    if (gemm_tile() >= 2 && gemm_tile() < 7) large = v;
+    if (gemm_tile() >= 7) large = false;
     if (large && (gemm_tile() == 0 || gemm_tile() == 2) && env_cached("VIMA_GEMM_PERSIST", g_gemm_persist, 1) && a.batch <= 1 &&
         a.K >= 2 * 64 && gemm_raster() == 0 && env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
@@ -1132,6 +1128,19 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       if (e >= 0) return e;
     }
     if (large) return launch_tile<T, TileL, true>(d, a, v, st);
+  }
+  if constexpr (sizeof(T) == 2) {
+    // Underfilled 128x128 grids (batch 1 .. 32: M = 8 .. 512) are bound by how fast ONE workgroup walks its K dimension
+    // (a 32-KiB slice per ~1400 clocks, most of the A tile being padding rows): smaller tiles move fewer bytes per slice
+    // and spread the problem over more CUs. Every tile shape accumulates K in the same order, so results do not depend
+    // on the choice.
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
+    if (v && gemm_tile() == 0 && env_cached("VIMA_GEMM_SMALL", g_gemm_small, 1) && t128 < 128) {
+      if (a.M <= 32) return launch_tile<T, TileXS, true>(d, a, v, st);
+      return launch_tile<T, Tile64, true>(d, a, v, st);
+    }
+    if (gemm_tile() == 7 && v) return launch_tile<T, TileXS, true>(d, a, v, st);
+    if (gemm_tile() == 8 && v) return launch_tile<T, Tile64, true>(d, a, v, st);
   }
   if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);
   return launch_tile<T, TileS, false>(d, a, v, st);
@@ -1153,6 +1162,7 @@ void set_gemm_tile(int v) { g_gemm_tile = v; }
 void set_gemm_raster(int v) { g_gemm_raster = v; }
 void set_gemm_epi(int v) { g_gemm_epi = v; }
 void set_gemm_persist(int v) { g_gemm_persist = v; }
+void set_gemm_small(int v) { g_gemm_small = v; }
 void set_gemm_dbg(long long* p) { g_gemm_dbg = p; }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
 

@@ -29,8 +29,9 @@ struct GemmArgs {
   // output-row remap (outputs only): orow = (r / rb) * s_hi + (r % rb) * s_lo + ro ; rb == 0 -> identity
   int rb = 0, s_hi = 0, s_lo = 0, ro = 0;
   // RMS statistics fused into the GEMMs either side of a T5 RMSNorm (the norm's weight is folded into W at pack time):
-  //   producer: ssq_out[r][j] = sum over columns [64j, 64j+64) of out[r][n]^2 (final fp32 values; needs out32, N % 64 == 0,
-  //             batch 1). Plain stores of N/64 partials per row -- no atomics, so the result is deterministic.
+  //   producer: ssq_out[r][j] = sum over columns [32j, 32j+32) of out[r][n]^2 (final fp32 values; needs out32, N % 32 == 0,
+  //             batch 1). Plain stores of N/32 partials per row -- no atomics, so the result is deterministic and the
+  //             same for every tile shape.
   //   consumer: accumulator row r is multiplied by rsqrt((sum_j rs_ssq[r][j], j < rs_parts) * rs_invk + rs_eps) before
   //             bias / activation
   float* ssq_out = nullptr;
@@ -54,6 +55,7 @@ void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default)
 void set_gemm_raster(int v);        // tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
 void set_gemm_epi(int v);           // 1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
 void set_gemm_persist(int v);       // 1 = large bf16 GEMMs on the persistent (one workgroup per CU) kernel (default), 0 = one tile per workgroup
+void set_gemm_small(int v);         // 1 = 64x64 / 32x64 tiles for underfilled grids (default), 0 = 128x128 only
 void set_gemm_dbg(long long* p);     // debug: device buffer [blocks*4] of shader-clock stamps (nullptr = off)
 void set_gemm_tile(int v);          // 0 = auto, 1 = 128x128 (TileS), 2 = 256x256 8 waves (TileL; persistent kernel unless gemm_persist=0)
 

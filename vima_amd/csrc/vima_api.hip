@@ -744,7 +744,7 @@ int t5_bias_table(VimaHandle* h, int L, float** out) {
   return 0;
 }
 
-struct T5Buf { void *hT, *qkv, *ctx, *u; float *ssA, *ssB; };   // ssA / ssB: RMS partial sums [rows][12] (fused path)
+struct T5Buf { void *hT, *qkv, *ctx, *u; float *ssA, *ssB; };   // ssA / ssB: RMS partial sums [rows][24] (fused path)
 
 void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B, int L,
               const T5Buf& b, int attn_impl) {
@@ -769,13 +769,13 @@ void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* ma
 //   * g lives in the consumer's weight (W diag(g), packed once),
 //   * the consumer reads the operand-type copy of the residual stream x (b.hT) that the PRODUCER of x wrote next to
 //     the fp32 stream, and scales its accumulator rows by rsqrt(sum x^2 / 768 + eps),
-//   * sum x^2 comes from the producer's epilogue as 12 per-64-column partials per row (deterministic, no atomics).
+//   * sum x^2 comes from the producer's epilogue as 24 per-32-column partials per row (deterministic, no atomics).
 // Entry: b.hT / ssq_in describe the incoming x (`parts_in` partials per row); exit: b.hT and the returned buffer
-// describe the outgoing x (12 partials). Removes two 600-MB HBM passes (fp32 read + bf16 write) per layer at cfg-3.
+// describe the outgoing x (24 partials). Removes two 600-MB HBM passes (fp32 read + bf16 write) per layer at cfg-3.
 const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B,
                             int L, const T5Buf& b, int attn_impl, const float* ssq_in, int parts_in) {
   const int rows = B * L;
-  constexpr int kParts = kT5Model / 64;
+  constexpr int kParts = kT5Model / 32;
   auto gemm = [&](const void* A, int lda, const Lin& W, int act, const float* res, float* out32, void* outT, int ldT,
                   const float* rs, int rs_parts, float* ssq_out) {
     GemmArgs g;
@@ -816,8 +816,8 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     buf[i].qkv = R.wsT(rows * 3 * kT5Model);
     buf[i].ctx = R.wsT(rows * kT5Model);
     buf[i].u = R.wsT(rows * kT5FF);
-    buf[i].ssA = R.ws<float>(rows * (kT5Model / 64));
-    buf[i].ssB = R.ws<float>(rows * (kT5Model / 64));
+    buf[i].ssA = R.ws<float>(rows * (kT5Model / 32));
+    buf[i].ssB = R.ws<float>(rows * (kT5Model / 32));
   }
   if (R.err) return R.err;
   Run Rb{h, h->aux};
@@ -840,7 +840,7 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     if (fused) {
       ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts);
       if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts);
-      parts = kT5Model / 64;
+      parts = kT5Model / 32;
     } else {
       t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
       if (dual) t5_layer(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl);
@@ -1079,6 +1079,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_epi") set_gemm_epi((int)value);
   else if (k == "gemm_persist") set_gemm_persist((int)value);
   else if (k == "gemm_splitk") set_gemm_splitk((int)value);
+  else if (k == "gemm_small") set_gemm_small((int)value);
   else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
   else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
   else if (k == "attn_dbg_ptr") set_attn_dbg(reinterpret_cast<long long*>((uintptr_t)value));
