@@ -1,0 +1,69 @@
+"""Env-step loop of scripts/example.py (reference lines 135-190) on the MI355X path, with synthetic inputs instead of
+the VIMA-Bench simulator (not installable offline): prompt encoded once per episode, then per env step
+observation tokens -> decoder -> action distribution -> embedded action for the next step.
+
+    python examples/episode_loop.py [--model 200M] [--batch 1] [--steps 8] [--refeed]
+
+--refeed reproduces the reference loop literally (the whole history goes through `forward` every step); the default
+uses `forward_step`, which processes only the newest tokens against the episode caches and gives the same predictions.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vima_amd import synthetic as syn                      # noqa: E402
+from vima_amd.policy import VIMAPolicy                    # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="200M")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--refeed", action="store_true")
+    args = ap.parse_args()
+    dev = "cuda:0"
+    cfg = syn.config(args.model, xattn_n_positions=512)
+    policy = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision="bf16", device=dev)
+    policy.load_state_dict(syn.make_state_dict(cfg, 0), strict=True)   # create_policy_from_ckpt(path, dev) with a real checkpoint
+    B = args.batch
+    prompt = syn.to_device(syn.make_prompt(B, n_segments=32, words_per_segment=8, q_per_view=4, seed=1), dev)
+    prompt_tokens, prompt_masks = policy.forward_prompt_assembly(prompt)          # once per episode
+    observations = [syn.to_device(syn.make_obs(1, B, 4, seed=100 + t), dev) for t in range(args.steps)]   # stands in for env.step()
+    for episode in range(2):                                                      # episode 0 warms up (workspace, caches)
+        ms = run_episode(policy, args, observations, prompt_tokens, prompt_masks)
+    print(ms)
+
+
+def run_episode(policy, args, observations, prompt_tokens, prompt_masks):
+    B = args.batch
+    obs_cache, act_cache = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        obs = observations[t]
+        obs_token, obs_mask = policy.forward_obs_token(obs)                       # [1,B,Q,E], [1,B,Q]
+        if args.refeed:
+            obs_cache.append((obs_token, obs_mask))
+            otok = torch.cat([o for o, _ in obs_cache]), torch.cat([m for _, m in obs_cache])
+            atok = torch.cat(act_cache) if act_cache else None
+            predicted = policy.forward(otok[0], otok[1], atok, prompt_tokens, prompt_masks)[-1]
+        else:
+            predicted = policy.forward_step(obs_token, obs_mask, act_cache[-1] if act_cache else None, prompt_tokens,
+                                            prompt_masks, step=t)
+        dists = policy.forward_action_decoder(predicted.unsqueeze(0))
+        actions = {k: v.mode() for k, v in dists.items()}                         # discrete bins, [1,B,n]
+        act_cache.append(policy.forward_action_token(actions))                    # [1,B,E] for the next step
+        continuous = policy._de_discretize_actions(actions)                       # what env.step() would receive
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    return (f"{args.model} batch {B}: {args.steps} env steps, {ms:.2f} ms per step ({'history re-fed' if args.refeed else 'incremental'}); "
+          f"last action pose0_position = {continuous['pose0_position'][0, 0].tolist()}")
+
+
+if __name__ == "__main__":
+    main()
