@@ -58,6 +58,30 @@ def test_matches_reference_golden(name, prec, attn_impl, gemm_variant, golden_di
             assert max_rel(got, ref) < 4e-2, (k, max_rel(got, ref))
 
 
+@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"graphs": 1},
+                                  {"dual_stream": 0}, {"attn_split": 0}, {"gemm_epi": 0}, {"vit_prune_last": 0}])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_every_option_matches_reference_golden(opts, prec, golden_dir):
+    """Each alternative code path (tile choice, one-tile-per-workgroup GEMM, split-K, unfused RMSNorm, graph replay, single
+    stream, one-wave cross attention, direct epilogue, full last ViT block) against the reference's golden outputs."""
+    name = "e384_long"
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    cfg, wseed, prompts, obs, actions = build_case(name)
+    sd = syn.make_state_dict(cfg, wseed)
+    pol = loaded_policy(cfg, sd, prec, **opts)
+    try:
+        for _ in range(3 if "graphs" in opts else 1):          # eager, capture, replay
+            out = native_outputs(pol, prompts, obs, actions)
+        ref = torch.from_numpy(gold["raw_logits"])
+        assert max_abs(out["raw_logits"].cpu(), ref) < 1e-3, (opts, max_abs(out["raw_logits"].cpu(), ref))
+        tok = torch.from_numpy(gold["prompt_tokens"])
+        assert max_rel(out["prompt_tokens"].cpu(), tok) < (2e-4 if prec == "fp32" else 4e-2)
+    finally:
+        for k in opts:                                         # GEMM / attention options are process-global
+            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "graphs": 0, "dual_stream": 1,
+                               "attn_split": 1, "gemm_epi": 1, "vit_prune_last": 1}[k])
+
+
 def test_stagewise_against_oracle_fp32():
     """Each native stage fed with the ORACLE's inputs for that stage (isolates stages from each other)."""
     cfg, wseed, prompts, obs, actions = build_case("ragged_4M")

@@ -940,7 +940,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.ntiles = (d.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
   d.raster = gemm_raster();
-  d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1);
+  d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1) || a.ssq_out != nullptr;   // the RMS partial sums exist only in the LDS epilogue
   d.dbg = g_gemm_dbg;
   {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
     const long long panel = (long long)TL::BN * a.K * (long long)sizeof(T);
