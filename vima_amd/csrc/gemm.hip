@@ -1116,7 +1116,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     // TileL when the 256x256 grid still fills the chip (>= ~1 workgroup per CU) and padding waste is small
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
-    bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 224) && waste < 1.15;
+    bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 160) && waste < 1.15;   // measured: 192 tiles of 256x256 beat 768 of 128x128 by 10-28 %
     if (gemm_tile() == 1) large = false;
     if (gemm_tile() >= 2 && gemm_tile() < 7) large = v;
     if (gemm_tile() >= 7) large = false;
