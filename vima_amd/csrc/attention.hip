@@ -3,8 +3,10 @@
 //  * vit_attn      : nn.MultiheadAttention(768, 24) over 5-token crop sequences (vit.py:203,217-231). One thread per
 //                    (crop, query token, head); everything in registers; HBM-bound.
 //  * attn_generic  : exact fp32-softmax attention for any operand type (parity mode + fallback), one wave per query.
-//  * attn_mfma     : bf16 flash attention on the matrix cores (online softmax, fp32 statistics), one wave per
-//                    32 queries x one head, covering the three flavours of the reference:
+//  * attn_mfma / attn_mfma4 / attn_split : bf16 flash attention on the matrix cores (online softmax in the log2 domain,
+//                    fp32 statistics): one wave per 32 queries (small shapes), 4 waves sharing LDS-staged K/V tiles
+//                    (>= 64 queries; V read with ds_read_b64_tr_b16), or 4 waves splitting the keys of <= 32 queries
+//                    (one env step of cross attention); head dims 32 / 64 (16 / 128 run on attn_generic). Flavours:
 //       ATTN_T5     T5Attention.forward (prompt_encoder.py:769-816): NO 1/sqrt(d); + (rel-bias[bucket(j-i)] + mask)
 //       ATTN_CROSS  XAttention.forward (components.py:184-214): /sqrt(d); + (1-mask)*finfo.min key mask
 //       ATTN_CAUSAL Attention._attn (components.py:51-80): /sqrt(d); w*b + -1e4*(1-b) causal fill; + key mask

@@ -5,18 +5,23 @@
 // T5DenseActDense wi/wo, nn/utils.py build_mlp Linear layers).
 //
 // Design (CDNA4, wave64):
-//  * Two tile shapes from one template:
-//      TileS 128x128, 4 waves (2x2, 64x64 per wave),  64 KiB LDS -> 2 workgroups/CU  (small / skinny problems, fp32 mode)
-//      TileL 256x256, 8 waves (2x4, 128x64 per wave), 128 KiB LDS -> 1 workgroup/CU  (the big bf16 GEMMs: half the
-//            LDS and L2 bytes per FLOP of TileS, 8 MFMAs per 6 ds_read_b128)
+//  * Tile shapes from one template (every shape accumulates K in the same order: results do not depend on the choice):
+//      TileL 256x256, 8 waves (2x4, 128x64 per wave), 128 KiB ring -> 1 workgroup/CU: the big bf16 GEMMs (half the LDS
+//            and L2 bytes per FLOP of TileS). Full-tile problems with one of the specialised epilogues run on the
+//            PERSISTENT kernel (gemm_persistent_kernel: one workgroup per CU, the K-slices of all its tiles form one
+//            LDS-DMA stream, epilogue through a private 32 KiB of LDS), the rest one tile per workgroup.
+//      TileS 128x128, 4 waves (2x2, 64x64 per wave), 64 KiB -> 2 workgroups/CU: mid-size problems, fp32 mode
+//      Tile64 64x64 (4 waves) / TileXS 32x64 (2 waves), 4-deep rings: grids that would leave most CUs idle (batch 1-32)
+//    Measured (profiles/r01_gemm_ablation.md): the 256x256 main loop is bound by the L2->LDS operand path (~19-25
+//    B/clk/CU with all CUs active), not by the matrix pipe; small grids by how fast one workgroup walks K.
 //  * K is consumed in 128-BYTE row slices (64 bf16 / 32 fp32): each tile row is 8 x 16 B chunks.
 //  * global -> LDS with `global_load_lds_dwordx4` (no VGPR round trip). The LDS image is lane-linear, so the
 //    bank-conflict swizzle is applied on the SOURCE address: LDS slot (row r, position p) receives global chunk
 //    c = p ^ ((r >> 1) & 7); fragments are read back with ds_read_b128 at position c ^ ((r >> 1) & 7).
 //    With 128-B rows every 16-lane ds_read_b128 group then touches 16 distinct 16-B slots of the 256-B bank row.
-//  * 2 LDS stages; the LDS-DMA of slice k+1 is issued (inline asm, hidden from hipcc's waitcnt bookkeeping so it is
+//  * 2 (4 for the small tiles) LDS stages; the LDS-DMA of slice k+1 is issued (inline asm, hidden from hipcc's waitcnt bookkeeping so it is
 //    NOT drained in front of the ds_reads) while slice k is multiplied; fragments of step kk+1 are prefetched into a
-//    second register set while the MFMAs of step kk run; ONE `s_waitcnt vmcnt(0)` + `s_barrier` per K-slice.
+//    second register set while the MFMAs of step kk run; ONE counted `s_waitcnt vmcnt(n)` + `s_barrier` per K-slice.
 //  * operands are fed SWAPPED to the matrix core (W fragment as A-operand, activation fragment as B-operand) so a
 //    lane ends up holding 4 CONSECUTIVE output columns of one output row -> 8/16-byte vector epilogue
 //    (bias / activation / GEGLU gate multiply / residual / dual fp32+bf16 store) instead of scalar stores.
