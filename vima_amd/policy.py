@@ -42,6 +42,38 @@ def _pair(a, b):
     return (ctypes.c_void_p * 2)(a, b)
 
 
+def build_prompt_index(raw_types, Q: int):
+    """Index form of the prompt assembly loops (vima_policy.py:168-233), vectorised per sample: for every sample the
+    output positions of its tokens in order, a word taking one slot and an image Q slots (front objects, then top
+    objects). Returns (src int32 [B, L_max], L_max, n_words, n_images) with src >= 0: index into word_batch; -1: padding;
+    <= -2: object slot -(image_index * Q + j) - 2. Raises ValueError for token types other than 0 / 1 like the reference
+    (vima_policy.py:177)."""
+    rows, L_max, wp, ip = [], 0, 0, 0
+    for p in raw_types:
+        t = np.asarray(p, dtype=np.int64).reshape(-1)
+        bad = t[(t != 0) & (t != 1)]
+        if bad.size:
+            raise ValueError(f"Invalid prompt token type {int(bad[0])}")
+        is_img = t == 1
+        lens = np.where(is_img, Q, 1)
+        starts = np.cumsum(lens) - lens
+        L_this = int(lens.sum())
+        row = np.empty(L_this, dtype=np.int32)
+        nw, ni = int((~is_img).sum()), int(is_img.sum())
+        row[starts[~is_img]] = wp + np.arange(nw, dtype=np.int32)
+        if ni and Q:
+            pos = (starts[is_img][:, None] + np.arange(Q)[None, :]).reshape(-1)
+            row[pos] = -(((ip + np.arange(ni))[:, None] * Q + np.arange(Q)[None, :]).reshape(-1) + 2)
+        wp += nw
+        ip += ni
+        rows.append(row)
+        L_max = max(L_max, L_this)
+    src = np.full((len(rows), max(L_max, 1)), -1, dtype=np.int32)
+    for b, row in enumerate(rows):
+        src[b, :row.shape[0]] = row
+    return src, L_max, wp, ip
+
+
 class VIMAPolicy(nn.Module):
     def __init__(self, *, embed_dim: int, xf_n_layers: int, sattn_n_heads: int, xattn_n_heads: int,
                  xattn_n_positions: int = 256, n_positions: int = 512, precision: str = "bf16", device=None):
@@ -252,31 +284,8 @@ class VIMAPolicy(nn.Module):
             except Exception:
                 qv = 0
         Q = 2 * qv
-        # index form of the assembly loops (vima_policy.py:168-233), vectorised per sample on the host
         B = len(raw_types)
-        rows, L_max, wp, ip = [], 0, 0, 0
-        for p in raw_types:
-            t = np.asarray(p, dtype=np.int64).reshape(-1)
-            bad = t[(t != 0) & (t != 1)]
-            if bad.size:
-                raise ValueError(f"Invalid prompt token type {int(bad[0])}")
-            is_img = t == 1
-            lens = np.where(is_img, Q, 1)
-            starts = np.cumsum(lens) - lens
-            L_this = int(lens.sum())
-            row = np.empty(L_this, dtype=np.int32)
-            nw, ni = int((~is_img).sum()), int(is_img.sum())
-            row[starts[~is_img]] = wp + np.arange(nw, dtype=np.int32)
-            if ni and Q:
-                pos = (starts[is_img][:, None] + np.arange(Q)[None, :]).reshape(-1)
-                row[pos] = -(((ip + np.arange(ni))[:, None] * Q + np.arange(Q)[None, :]).reshape(-1) + 2)
-            wp += nw
-            ip += ni
-            rows.append(row)
-            L_max = max(L_max, L_this)
-        src = np.full((B, max(L_max, 1)), -1, dtype=np.int32)
-        for b, row in enumerate(rows):
-            src[b, :row.shape[0]] = row
+        src, L_max, wp, ip = build_prompt_index(raw_types, Q)
         if wp > word_batch.numel() or ip > n_img:
             raise IndexError("prompt token types reference more words / images than provided")
         word_batch = word_batch.to(device=dev, dtype=torch.int64).contiguous()
