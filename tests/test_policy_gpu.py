@@ -223,6 +223,29 @@ def test_incremental_decoding_matches_full_history(prec, cfgname, T):
     assert max_rel(pol.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV)), full) < 1e-6
 
 
+def test_incremental_decoding_full_size_200m():
+    """VIMA-200M, batch 64, 512-token prompt, T = 3: the episode-cache path against the re-fed history at the
+    benchmark's model size (persistent / 128x128 / 64x64 GEMM tiles and the split-key attention kernel all take part)."""
+    cfg = syn.config("200M", xattn_n_positions=512)
+    sd = syn.make_state_dict(cfg, 0)
+    pol = loaded_policy(cfg, sd, "bf16")
+    g = torch.Generator().manual_seed(8)
+    B, Lp, Q, E, T = 64, 512, 8, cfg.embed_dim, 3
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = torch.ones(B, Lp, dtype=torch.bool, device=DEV)
+    pmask[5, 400:] = False
+    otok = torch.randn(T, B, Q, E, generator=g).to(DEV)
+    omask = torch.ones(T, B, Q, dtype=torch.bool, device=DEV)
+    omask[1, :, 3] = False
+    atok = torch.randn(T - 1, B, E, generator=g).to(DEV)
+    full = pol.forward(otok, omask, atok, ptok, pmask)
+    for t in range(T):
+        step = pol.forward_step(otok[t], omask[t], atok[t - 1] if t > 0 else None, ptok, pmask, t)
+        assert torch.isfinite(step).all()
+        assert max_rel(step, full[t]) < 4e-2, (t, max_rel(step, full[t]))
+        assert max_abs(pol.action_logits(step), pol.action_logits(full[t])) < 1e-3
+
+
 @pytest.mark.parametrize("heads", [16, 2])
 def test_other_head_counts_against_oracle(heads):
     """embed_dim 256 with 16 heads (head dim 16) and 2 heads (head dim 128): the head counts are free parameters of
