@@ -92,3 +92,17 @@ def test_algorithmic_flops_of_the_headline_config():
     cold, warm = bench.flops_per_sample(768, 11, 512, 32 * 8, 8, 1)
     assert abs(cold / 1e9 - 191.74) < 0.05          # 191.74 GFLOP/sample -> 49.09 TFLOP per B=256 step
     assert 0 < warm < cold
+
+
+def test_bench_helpers_without_gpu():
+    """bench.py pieces that do not need the GPU: the committed PMC traffic figure it reports as roofline.traffic, the
+    usable-core probe of the CPU baseline and the argument defaults of the driver contract (N=1, K/W that finish fast)."""
+    import inspect
+    import bench
+    t = bench.pmc_traffic()
+    assert t is None or t > 1e6                    # bytes per GEMM launch from profiles/r*_pmc_traffic.json
+    assert bench.usable_cores() >= 1
+    src = inspect.getsource(bench.main)
+    for flag, default in (("--gpus", "default=1"), ("--steps", "default=5"), ("--warmup", "default=2")):
+        line = next(l for l in src.splitlines() if f'"{flag}"' in l)
+        assert default in line, line
