@@ -1,0 +1,44 @@
+"""Compile-time resource guard (no GPU): the hot kernels must not use scratch memory. hipcc once kept a staging array
+of the attention kernels in scratch (a vmcnt(0) + scratch round trip behind every global load) and spilled the
+all-runtime persistent GEMM epilogue -- both cost 5-10 % silently. Cross-compiles the two sources for gfx950 with
+-Rpass-analysis=kernel-resource-usage and checks ScratchSize / VGPR budget of the kernels the benchmark runs on."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _usage(src):
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
+                          "--cuda-device-only", "-c", os.path.join(ROOT, "vima_amd", "csrc", src), "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            res[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            res[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    return res
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,patterns", [("gemm.hip", ["gemm_persistent_kernel", "gemm_kernelItNS0_4TileILi256ELi256"]),
+                                          ("attention.hip", ["attn_mfma4_kernel", "attn_split_kernel"])])
+def test_hot_kernels_use_no_scratch(src, patterns):
+    res = _usage(src)
+    # the scalar-epilogue fallback instantiations (VEC = false: N % 4 != 0) are not on the benchmark's path
+    hot = {k: v for k, v in res.items() if any(p in k for p in patterns) and "ELb0ELb1EEEv" not in k}
+    assert hot, f"no kernel of {src} matched {patterns}"
+    for k, v in hot.items():
+        assert v.get("ScratchSize", 0) == 0, (k, v)
+        assert v.get("VGPRs", 0) + v.get("AGPRs", 0) <= 256, (k, v)     # two waves per SIMD for the 512-thread GEMMs
