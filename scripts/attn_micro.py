@@ -33,7 +33,7 @@ def main():
     for _ in range(iters):
         _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 1, p(out), pol._stream()))
     torch.cuda.synchronize()
-    if os.environ.get("STAMPS"):
+    if os.environ.get("STAMPS"):   # needs a library built with -DVIMA_ATTN_STAMPS=1 (scripts/gpu_job_attn_ablate.sh pattern)
         nwg = B * H * ((Lq + 127) // 128) + 64
         dbg = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
         pol.set_option("attn_dbg_ptr", dbg.data_ptr())

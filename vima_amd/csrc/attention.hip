@@ -519,11 +519,20 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
   gload(0);
   lstore(0);
   __syncthreads();
+  // per-phase shader-clock stamps of wave 0 (scripts/attn_micro.py STAMPS=1): compiled in only with -DVIMA_ATTN_STAMPS=1,
+  // a run-time switch would split the loop body into basic blocks and pin the instruction schedule at every mark
+#ifndef VIMA_ATTN_STAMPS
+#define VIMA_ATTN_STAMPS 0
+#endif
   long long ph[6] = {0, 0, 0, 0, 0, 0};
-  auto now = [&]() { return (long long)__builtin_readcyclecounter(); };
-  const bool dbg = p.dbg != nullptr;
-  long long t_prev = dbg ? now() : 0;
-  auto mark = [&](int i) { if (dbg) { const long long t = now(); ph[i] += t - t_prev; t_prev = t; } };
+  constexpr bool kStamps = VIMA_ATTN_STAMPS != 0;
+  const bool dbg = kStamps && p.dbg != nullptr;
+  long long t_prev = dbg ? (long long)__builtin_readcyclecounter() : 0;
+  auto mark = [&](int i) {
+    if constexpr (kStamps) {
+      if (dbg) { const long long t = (long long)__builtin_readcyclecounter(); ph[i] += t - t_prev; t_prev = t; }
+    }
+  };
 
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
