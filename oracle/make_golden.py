@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shim                       # noqa: E402
-from oracle.cases import CASES, build_case, run_policy  # noqa: E402
+from oracle.cases import CASES, build_case, run_policy, case_state_dict, gold_view, gold_keys  # noqa: E402
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS  # noqa: E402
 from vima_amd import synthetic as syn            # noqa: E402
 
@@ -34,10 +34,13 @@ def main():
     torch.set_num_threads(os.cpu_count())
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    only = sys.argv[1:]
     for name in CASES:
+        if only and name not in only:
+            continue
         t0 = time.time()
         cfg, wseed, prompts, obs, actions = build_case(name)
-        sd = syn.make_state_dict(cfg, wseed)
+        sd = case_state_dict(name, cfg)
         pol = ref_shim.build_reference_policy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions)
         missing = pol.load_state_dict(sd, strict=True)   # validates the Appendix-B key/shape contract
         pol.eval()
@@ -68,7 +71,7 @@ def main():
             else:
                 diff = (a - b).abs().max().item()
                 print(f"   {k:20s} {tuple(a.shape)} max|ref|={a.abs().max().item():.4g} max|oracle-ref|={diff:.3g}")
-        arrays = {k: v.detach().cpu().numpy() for k, v in out.items()}
+        arrays = {k: gold_view(name, k, out[k]).detach().cpu().numpy() for k in gold_keys(name, out)}
         arrays["_sd_checksum"] = np.float64(syn.state_dict_checksum(sd))
         arrays["_torch_version"] = np.array(torch.__version__)
         np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **arrays)

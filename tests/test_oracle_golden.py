@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.cases import CASES, build_case, run_policy
+from oracle.cases import CASES, build_case, run_policy, case_state_dict, gold_view
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS, t5_relative_position_bucket
 from vima_amd import synthetic as syn
 
@@ -18,7 +18,7 @@ ATOL = 5e-5
 def test_oracle_matches_reference_golden(name, golden_dir):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     cfg, wseed, prompts, obs, actions = build_case(name)
-    sd = syn.make_state_dict(cfg, wseed)
+    sd = case_state_dict(name, cfg)
     assert abs(syn.state_dict_checksum(sd) - float(gold["_sd_checksum"])) <= 1e-6 * float(gold["_sd_checksum"]), \
         "seeded weights drifted from the ones the fixtures were generated with"
     orc = OraclePolicy(sd, **cfg.ctor_kwargs())
@@ -31,7 +31,7 @@ def test_oracle_matches_reference_golden(name, golden_dir):
         if k.startswith("_"):
             continue
         ref = torch.from_numpy(gold[k])
-        got = out[k]
+        got = gold_view(name, k, out[k])
         assert tuple(got.shape) == tuple(ref.shape), k
         if ref.dtype in (torch.bool, torch.int64):
             assert torch.equal(got, ref), k

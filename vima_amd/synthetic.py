@@ -115,8 +115,10 @@ class _Init:
             self.linear(f"{prefix}.{3 * i}", out_f, in_f, g / math.sqrt(max(in_f, out_f)))
 
 
-def make_state_dict(cfg: PolicyConfig, seed: int = 0) -> dict[str, torch.Tensor]:
-    """State dict with the reference `VIMAPolicy` key layout."""
+def make_state_dict(cfg: PolicyConfig, seed: int = 0, head_gain: float = 0.01) -> dict[str, torch.Tensor]:
+    """State dict with the reference `VIMAPolicy` key layout. `head_gain` is the orthogonal gain
+    of the action head's output layers (reference: 0.01, action_decoder.py:150-153 -> logits O(0.06)); the parity
+    suite also runs a gain-0.5 variant whose logits are O(1) so that argmax agreement is a meaningful check."""
     E, N = cfg.embed_dim, cfg.xf_n_layers
     I = _Init(seed)
     # ---- xattn_gpt (xattn_gpt.py:45-68, components.py) ----
@@ -188,7 +190,7 @@ def make_state_dict(cfg: PolicyConfig, seed: int = 0) -> dict[str, torch.Tensor]
     # ---- action decoder (action_decoder.py:128-166) ----
     for k in ACTION_KEYS:
         for j, bins in enumerate(ACTION_DIMS[k]):
-            I.mlp(f"action_decoder._decoders.{k}.mlps.{j}", [E, 512, 512, bins], last_gain=0.01)
+            I.mlp(f"action_decoder._decoders.{k}.mlps.{j}", [E, 512, 512, bins], last_gain=head_gain)
     # ---- word embedding + T5 encoder (word_embd.py, prompt_encoder.py) ----
     I.normal("prompt_embedding._embed_layer.weight", (T5_VOCAB, 768), 1.0)
     t5 = "t5_prompt_encoder.t5."
@@ -277,6 +279,32 @@ def make_prompt(batch: int, layout: list[list[int]] | None = None, *, n_segments
     word_batch = torch.randint(0, 32100, (n_words,), generator=g)
     image_batch = _objects(g, (max(n_img, 0),), q_per_view, mask_frac)
     return layout, word_batch, image_batch
+
+
+def cut_prompt(prompts, idx):
+    """Sub-batch `idx` (sample indices) of a `make_prompt` triple: words and images are packed per sample in prompt
+    order, so sample s owns a contiguous run of each."""
+    layout, words, imgs = prompts
+    nw = [sum(t == 0 for t in p) for p in layout]
+    ni = [sum(t == 1 for t in p) for p in layout]
+    w0 = [0]
+    i0 = [0]
+    for a, b in zip(nw, ni):
+        w0.append(w0[-1] + a)
+        i0.append(i0[-1] + b)
+    wsel = torch.cat([words[w0[s]:w0[s + 1]] for s in idx]) if len(idx) else words[:0]
+    isel = MapDict({k: MapDict({v: torch.cat([imgs[k][v][i0[s]:i0[s + 1]] for s in idx]) for v in imgs[k]}) for k in imgs})
+    return [layout[s] for s in idx], wsel, isel
+
+
+def cut_obs(obs, idx):
+    """Sub-batch `idx` of a `make_obs` dict (batch is dim 1)."""
+    return {"objects": MapDict({k: MapDict({v: obs["objects"][k][v][:, idx] for v in obs["objects"][k]})
+                                for k in obs["objects"]}), "ee": obs["ee"][:, idx]}
+
+
+def cut_actions(actions, idx):
+    return None if actions is None else {k: v[:, idx] for k, v in actions.items()}
 
 
 def prompt_len(layout, q_per_view):
