@@ -9,7 +9,8 @@ VIMA-200M, batch 256 per GPU, 512-token prompt (32 x [8 words + 1 image -> 8 obj
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
 
 Multi-GPU = data parallel, weak scaling: every rank evaluates its own batch of 256 with a full weight replica and the
-only collective is one all-gather of the [256,700] logits per step (vima_amd/parallel.py).
+only collective is one all-gather of the [256,700] logits per step (vima_allgather_logits in the C ABI, RCCL over xGMI).
+`python bench.py --gpus N` on its own re-launches itself with N ranks; it exits non-zero when fewer than N GPUs are visible.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -138,20 +139,44 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (vima_set_option), repeatable")
     args = ap.parse_args()
 
+    # ---- N ranks: `--gpus N` without a torchrun environment re-launches this script under torch.distributed.run with one
+    # rank per GPU; it never silently measures fewer GPUs than asked for.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible on this node; refusing to "
+                     f"print a {visible}-GPU number as a {args.gpus}-GPU result")
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()                  # the LIVE RCCL world size is what gets reported as n_gpus
 
     from vima_amd import synthetic as syn, parallel
     from vima_amd.policy import VIMAPolicy
+    if world > 1:
+        comm = parallel.LogitsComm(dev)                # RCCL communicator behind the C ABI (vima_allgather_logits)
+        assert comm.world == world
 
     Q = 2 * args.qv
     seg_len = args.words + Q                         # words + 1 image (Q object tokens) per segment
@@ -176,7 +201,7 @@ def main():
         atok = pol.forward_action_token(past) if past is not None else None
         pred = pol.forward(otok, omask, atok, ptok, pmask)
         logits = pol.action_logits(pred[-1])
-        return parallel.all_gather_logits(logits, global_batch=B * world) if world > 1 else logits
+        return parallel.all_gather_logits(logits, global_batch=B * world, comm=comm) if world > 1 else logits
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -292,6 +317,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        comm.close()
         dist.destroy_process_group()
 
 

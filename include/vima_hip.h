@@ -121,6 +121,25 @@ int vima_action_head(VimaHandle* h, const float* tokens, int R, float* out_logit
  * pose1_rotation [R,4] -> out f32 [R,E]. */
 int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int R, float* out, vima_stream_t stream);
 
+/* ---- multi-GPU: the one exchange step of the data-parallel path ----------------------------------- */
+/* The reference has no distributed code (no torch.distributed / NCCL call site anywhere under vima/); batched episodes
+ * are independent, so the path shards over one process per GPU with a full weight replica and ONE collective per
+ * step: an all-gather of the raw action logits (the output of vima_action_head) over RCCL / xGMI.
+ * vima_comm_unique_id: rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks
+ * out of band (the Python host broadcasts it through the torch.distributed store);
+ * vima_comm_create: every rank joins (ncclCommInitRank) on its own `device`;
+ * vima_allgather_logits: local f32 [rows_per_rank, width] -> global f32 [world * rows_per_rank, width] on every
+ * rank, enqueued on `stream` (no host synchronisation). Equal shard sizes (the host pads ragged tails). */
+#define VIMA_COMM_ID_BYTES 128
+typedef struct VimaComm VimaComm;
+int vima_comm_unique_id(uint8_t id[VIMA_COMM_ID_BYTES]);
+int vima_comm_create(const uint8_t id[VIMA_COMM_ID_BYTES], int world, int rank, int device, VimaComm** out);
+int vima_comm_world(const VimaComm* c);
+int vima_comm_rank(const VimaComm* c);
+int vima_allgather_logits(VimaComm* c, const float* local, float* global, int64_t rows_per_rank, int width,
+                          vima_stream_t stream);
+void vima_comm_destroy(VimaComm* c);
+
 /* ---- operator-level entry points (parity tests / microbenchmarks) ---------------------------------------------- */
 /* out = epilogue(A[M,K] . W[N,K]^T) in the handle's precision; fp32 host-visible device buffers in/out, the
  * operand conversion is done internally. act: 0 none, 1 relu, 2 gelu(erf), 3 quickgelu. bias/mul/res may be NULL. */

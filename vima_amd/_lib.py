@@ -55,7 +55,14 @@ PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_double)]),
     "vima_workspace_bytes": (c_i64, [vp]),
     "vima_graph_stats": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "vima_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "vima_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
+    "vima_comm_world": (ctypes.c_int, [vp]),
+    "vima_comm_rank": (ctypes.c_int, [vp]),
+    "vima_allgather_logits": (ctypes.c_int, [vp, vp, vp, c_i64, ctypes.c_int, vp]),
+    "vima_comm_destroy": (None, [vp]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -39,6 +39,12 @@ int fail(const std::string& m, int code = 1) {
       return fail(std::string(#expr) + ": " + hipGetErrorString((hipError_t)e__) + " @" + __func__, e__); \
   } while (0)
 
+}  // namespace
+namespace vima {
+int api_fail(const std::string& m) { return fail(m); }   // for the other translation units of the C ABI (comm.hip)
+}
+namespace {
+
 constexpr int kVitW = 768, kVitLayers = 4, kVitHeads = 24;
 constexpr int kT5Layers = 12, kT5Heads = 12, kT5D = 64, kT5FF = 3072, kT5Model = 768, kT5Buckets = 32;
 constexpr int kVocab = 32128;

@@ -5,11 +5,69 @@ end-to-end, so the batch shards with no activation exchange: each rank holds a f
 runs the policy on its contiguous slice of the batch and the only collective is ONE all-gather of the
 [B_local, 700] fp32 raw logits (RCCL over xGMI when the backend is "nccl"; "gloo" for the CPU tests) --
 5.7 MB at global batch 2048, latency-bound, so the plain ring/direct all-gather RCCL picks is fine.
+
+On the GPU the collective goes through the C ABI (`vima_allgather_logits` in include/vima_hip.h, RCCL bound inside
+libvima_hip.so): `LogitsComm` creates the communicator -- rank 0 draws the RCCL unique id (`vima_comm_unique_id`), the id
+travels to the other ranks through the already initialised torch.distributed group (plumbing), every rank joins with
+`vima_comm_create`. Without a `LogitsComm` (CPU tests, gloo) the same function falls back to torch.distributed.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+
+class LogitsComm:
+    """RCCL communicator of the data-parallel policy path, owned by libvima_hip.so (C ABI: vima_comm_*)."""
+
+    def __init__(self, device, group=None, rank: int | None = None, world: int | None = None, unique_id: bytes | None = None):
+        from . import _lib
+        self._lib = _lib.load()
+        self._check = _lib.check
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("LogitsComm needs a GPU device (RCCL); the CPU tests use torch.distributed/gloo instead")
+        self.device = device
+        if rank is None or world is None:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world = rank, world
+        if unique_id is None:
+            box = [None]
+            if rank == 0:
+                buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+                self._check(self._lib.vima_comm_unique_id(buf))
+                box[0] = buf.raw
+            if world > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            unique_id = box[0]
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        h = ctypes.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self._check(self._lib.vima_comm_create(unique_id, world, rank, idx, ctypes.byref(h)))
+        self._h = h
+
+    def all_gather(self, local: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
+        """local f32 [rows_per_rank, W] (contiguous, on this rank's GPU) -> [world * rows_per_rank, W]; enqueued on the
+        current stream, no host synchronisation."""
+        assert local.is_cuda and local.dtype == torch.float32 and local.is_contiguous() and local.shape[0] == rows_per_rank
+        out = local.new_empty(self.world * rows_per_rank, local.shape[1])
+        stream = ctypes.c_void_p(torch.cuda.current_stream(local.device).cuda_stream)
+        self._check(self._lib.vima_allgather_logits(self._h, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                    rows_per_rank, local.shape[1], stream))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.vima_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -31,11 +89,30 @@ def shard_batch_dim(x, dim: int, rank: int, world: int):
     return x
 
 
-def all_gather_logits(local: torch.Tensor, group=None, global_batch: int | None = None) -> torch.Tensor:
-    """[B_local, W] -> [B_global, W] on every rank. Uneven shards are padded to the largest shard for the collective."""
+def all_gather_logits(local: torch.Tensor, group=None, global_batch: int | None = None,
+                      comm: LogitsComm | None = None) -> torch.Tensor:
+    """[B_local, W] -> [B_global, W] on every rank. Uneven shards are padded to the largest shard for the collective.
+    With `comm` the exchange is `vima_allgather_logits` (RCCL inside the C ABI); without it torch.distributed."""
+    if comm is not None:
+        world = comm.world
+        if world == 1:
+            return local
+        if global_batch is None:
+            raise ValueError("global_batch is required with a LogitsComm (shard sizes must be known without a collective)")
+        counts = [shard_bounds(global_batch, r, world)[1] - shard_bounds(global_batch, r, world)[0] for r in range(world)]
+        mx = max(counts)
+        padded = local.contiguous()
+        if local.shape[0] < mx:
+            padded = torch.cat([local, local.new_zeros(mx - local.shape[0], *local.shape[1:])], dim=0)
+        out = comm.all_gather(padded, mx)
+        if all(c == mx for c in counts):
+            return out
+        return torch.cat([out[r * mx: r * mx + c] for r, c in enumerate(counts)], dim=0)
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":   # 2 ranks sharing one GPU in the tests: exchange on the host
+        return all_gather_logits(local.cpu(), group=group, global_batch=global_batch).to(local.device)
     if global_batch is None:
         sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
         dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
@@ -53,10 +130,10 @@ def all_gather_logits(local: torch.Tensor, group=None, global_batch: int | None 
     return torch.cat([out[r * mx: r * mx + c] for r, c in enumerate(counts)], dim=0)
 
 
-def data_parallel_logits(step_fn, global_batch: int, group=None) -> torch.Tensor:
+def data_parallel_logits(step_fn, global_batch: int, group=None, comm: LogitsComm | None = None) -> torch.Tensor:
     """Run `step_fn(lo, hi) -> [hi-lo, W] logits` on this rank's shard of `global_batch` samples and return the
     gathered [global_batch, W] logits (identical on every rank)."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     lo, hi = shard_bounds(global_batch, rank, world)
-    return all_gather_logits(step_fn(lo, hi), group=group, global_batch=global_batch)
+    return all_gather_logits(step_fn(lo, hi), group=group, global_batch=global_batch, comm=comm)
