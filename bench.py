@@ -118,7 +118,10 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
     samples_per_s = cb / cdt
     return {"value": round(samples_per_s / B, 6), "unit": "steps/s", "cores": best_t, "kind": "port",
             "sample": f"oracle (torch fp32 restatement of the reference's CPU path), same VIMA-200M cold workload at batch {cb} "
-                      f"({it} timed pass(es), {cdt:.2f} s each = {samples_per_s:.3f} samples/s), expressed in batch-{B} steps/s",
+                      f"({it} timed pass(es), {cdt:.2f} s each = {samples_per_s:.3f} samples/s), expressed in batch-{B} steps/s. "
+                      "NOT in the timed port: the reference's O(B*Lp) Python prompt-assembly loop (vima_policy.py:168-233; the "
+                      "oracle assembles with index ops) and its DataDict plumbing -- the reference itself is slower than this; "
+                      "/root/reference does not exist on the GPU box, so the shimmed reference cannot be timed there",
             "usable_cores": ncores, "host_cpu_count": os.cpu_count(), "threads_tried": cands}
 
 
@@ -262,6 +265,39 @@ def main():
     sync()
     inc_ms = (time.perf_counter() - t0) / 8 * 1e3
 
+    # ---- north_star's other batch sizes, driver-visible in the same run: COLD steps at batch 1 and 32 of
+    # the same model / prompt, each with the roofline that binds it (batch 1: the ~676 MB of bf16 weights over HBM;
+    # batch 32: bf16 MFMA)
+    secondary = {}
+    WEIGHT_BYTES = 676e6 if args.precision == "bf16" else 1352e6          # weights touched once per pass
+    for b2 in (1, 32):
+        if b2 >= B:
+            continue
+        p2 = syn.to_device(syn.make_prompt(b2, n_segments=n_seg, words_per_segment=args.words, q_per_view=args.qv, seed=1236 + rank), dev)
+        o2 = syn.to_device(syn.make_obs(1, b2, args.qv, seed=1336 + rank), dev)
+
+        def step2():
+            ptok, pmask = pol.forward_prompt_assembly(p2)
+            otok, omask = pol.forward_obs_token(o2)
+            return pol.action_logits(pol.forward(otok, omask, None, ptok, pmask)[-1])
+
+        step2()
+        step2()
+        sync()
+        n2 = max(args.steps, 5)
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            step2()
+        sync()
+        ms2 = (time.perf_counter() - t0) / n2 * 1e3
+        cold2, _ = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, 1)
+        t_mfma = b2 * cold2 / ((BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS) * 1e12) * 1e3
+        t_hbm = WEIGHT_BYTES / 8e12 * 1e3
+        secondary[f"batch_{b2}"] = {
+            "ms_per_step": round(ms2, 3), "steps_per_s": round(1e3 / ms2, 2), "samples_per_s": round(b2 * 1e3 / ms2, 1),
+            "bound": "hbm" if t_hbm > t_mfma else "mfma", "roofline_ms": round(max(t_hbm, t_mfma), 4),
+            "roofline_frac": round(max(t_hbm, t_mfma) / ms2, 4)}
+
     # ---- per-class kernel time (HIP events on the launch stream), same workload, outside the timed region. The
     # two-stream software pipelining is switched off for this pass so that kernels do not overlap each other and the
     # event-bracketed durations are those of the kernels alone (what rocprofv3 --kernel-trace reports for the
@@ -311,7 +347,8 @@ def main():
                        "samples_per_s": round(world * B * args.steps / dt, 1),
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),
                        "warm_ms_per_step": round(warm_ms, 3), "warm_steps_per_s": round(world * 1e3 / warm_ms, 2),
-                       "incremental_env_step_ms": round(inc_ms, 3)},
+                       "incremental_env_step_ms": round(inc_ms, 3),
+                       "secondary_cold": secondary},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

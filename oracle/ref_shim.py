@@ -74,6 +74,26 @@ def load_reference():
             return func(*structs)
 
         tree.map_structure = map_structure
+
+        def traverse(fn, structure, top_down=True):
+            """Minimal dm-tree `traverse`: visit every sub-structure; a non-None return value replaces it (bottom-up:
+            children first). Only what vima/utils.py::_wrap_datadict needs."""
+            import collections.abc as cabc
+            if top_down:
+                r = fn(structure)
+                if r is not None:
+                    return r
+            if isinstance(structure, cabc.Mapping):
+                structure = type(structure)({k: traverse(fn, v, top_down) for k, v in structure.items()})
+            elif isinstance(structure, (list, tuple)):
+                structure = type(structure)(traverse(fn, v, top_down) for v in structure)
+            if not top_down:
+                r = fn(structure)
+                if r is not None:
+                    return r
+            return structure
+
+        tree.traverse = traverse
     import transformers.models.t5.modeling_t5 as mt5
     from transformers import T5Config
 

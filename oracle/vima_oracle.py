@@ -243,8 +243,10 @@ class OraclePolicy:
         sd = self.sd
         a = self._de_discretize_actions(action)
         parts = [_mlp(sd, f"action_encoder._embed_dict.{k}._layer", a[k], 2) for k in sorted(a.keys())]
-        return _lin(torch.cat(parts, dim=-1), sd["action_encoder._post_layer.weight"],
-                    sd["action_encoder._post_layer.bias"])
+        x = torch.cat(parts, dim=-1)
+        if "action_encoder._post_layer.weight" not in sd:   # nn.Identity when embed_dim == 4 * 256 (action_embd.py:16-20)
+            return x
+        return _lin(x, sd["action_encoder._post_layer.weight"], sd["action_encoder._post_layer.bias"])
 
     def action_logits(self, tokens):
         """Raw concatenated MLP outputs, width 700, key order of ACTION_KEYS (action_decoder.py:165-166)."""

@@ -73,3 +73,16 @@ def test_bad_config_raises_value_error():
     from vima_amd.policy import VIMAPolicy
     with pytest.raises(ValueError):
         VIMAPolicy(embed_dim=250, xf_n_layers=1, sattn_n_heads=8, xattn_n_heads=8)
+
+
+def test_embed_dim_1024_has_no_action_post_layer():
+    """ActionEmbedding._post_layer is nn.Identity when embed_dim == 4 * 256 (action_embd.py:16-20): the key must not be
+    demanded by the strict loader, and the synthetic state dict must satisfy the key contract."""
+    from vima_amd.policy import VIMAPolicy
+    cfg = syn.PolicyConfig(1024, 1, 16, 16)
+    pol = VIMAPolicy(**cfg.ctor_kwargs())
+    req, ign = pol.expected_keys()
+    assert not any(k.startswith("action_encoder._post_layer") for k in req)
+    assert "t5_prompt_encoder_post_layer.weight" in req
+    sd = syn.make_state_dict(cfg, 0)
+    assert set(req) <= set(sd) and not (set(sd) - set(req) - set(ign))

@@ -106,3 +106,32 @@ def test_bench_helpers_without_gpu():
     for flag, default in (("--gpus", "default=1"), ("--steps", "default=5"), ("--warmup", "default=2")):
         line = next(l for l in src.splitlines() if f'"{flag}"' in l)
         assert default in line, line
+
+
+def test_obj_inputs_accept_the_reference_datadict():
+    """The boundary is fed by the reference's own container in scripts/example.py (`vima.utils.DataDict`,
+    /root/reference/vima/utils.py:228, a MutableMapping that is NOT a dict subclass): VIMAPolicy._obj_inputs must flatten
+    and order it exactly like the plain-dict path. Needs the reference tree (build container only)."""
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("reference tree not present")
+    ref_shim.load_reference()
+    from vima.utils import DataDict
+    cfg = syn.config("2M")
+    pol = VIMAPolicy(**cfg.ctor_kwargs())
+    obs = syn.make_obs(2, 3, 2, seed=3)
+    plain = {k: {v: t for v, t in d.items()} for k, d in obs["objects"].items()}
+    dd = DataDict({"objects": plain, "ee": obs["ee"]})
+    assert isinstance(dd["objects"], DataDict) and not isinstance(dd["objects"], dict)
+    a = pol._obj_inputs(dd["objects"], 2)
+    b = pol._obj_inputs(obs["objects"], 2)
+    assert a[3:] == b[3:] == (6, 2)
+    for xs, ys in zip(a[:3], b[:3]):
+        for x, y in zip(xs, ys):
+            assert x.dtype == y.dtype and torch.equal(x, y)
+    # the prompt side indexes image_batch the same way (vima_policy.py:164,193)
+    imgs = syn.make_prompt(2, n_segments=2, words_per_segment=1, q_per_view=2, seed=4)[2]
+    dd_img = DataDict({k: {v: t for v, t in d.items()} for k, d in imgs.items()})
+    for xs, ys in zip(pol._obj_inputs(dd_img, 1)[:3], pol._obj_inputs(imgs, 1)[:3]):
+        for x, y in zip(xs, ys):
+            assert torch.equal(x, y)

@@ -147,7 +147,6 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
 }
 
 // =============================================================================================== generic exact kernel
-long long* g_attn_dbg = nullptr;
 
 struct AttnDev {
   const void* q; int ldq;
@@ -400,15 +399,9 @@ __device__ __forceinline__ int kswz(int r, int c) {
   return c ^ ((r >> 2) & 3);                // 64-B rows, 4 chunks
 }
 
-#ifndef VIMA_ATTN_ABLATE
-#define VIMA_ATTN_ABLATE 0
-#endif
-#ifndef VIMA_ATTN_OCC
-#define VIMA_ATTN_OCC 3
-#endif
-// experiment only (wrong results): VIMA_ATTN_ABLATE 1 = no per-tile barrier, 2 = no softmax VALU work, 4 = no PV MFMAs
+// (phase ablations of this kernel -- timing only, wrong results -- live in scripts/ablate/attn_ablate.patch)
 template <int D, int MODE>
-__global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_kernel(const AttnDev p) {
+__global__ __launch_bounds__(256, D == 32 ? 4 : 3) void attn_mfma4_kernel(const AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
   constexpr int KD = D / 16, OT = D / 32, CPR = D / 8;       // k-steps, O^T tiles, 16-B chunks per K/V row
   constexpr int ROWB = D * 2;
@@ -612,8 +605,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = (VIMA_ATTN_ABLATE & 2) ? x[sub][r] : __builtin_amdgcn_exp2f(x[sub][r] - m_run);
-        const float p1 = (VIMA_ATTN_ABLATE & 2) ? x[sub][r + 1] : __builtin_amdgcn_exp2f(x[sub][r + 1] - m_run);
+        const float p0 = __builtin_amdgcn_exp2f(x[sub][r] - m_run);
+        const float p1 = __builtin_amdgcn_exp2f(x[sub][r + 1] - m_run);
         pk[sub][r >> 1] = pack2_bf16(p0, p1);
         rs += p0 + p1;
       }
@@ -642,7 +635,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : VIMA_ATTN_OCC) void attn_mfma4_k
     mark(3);   // PV MFMAs issued
     if (t + 1 < nt) lstore(buf ^ 1);
     mark(4);   // next tile written to LDS (waits for its global loads)
-    if (!(VIMA_ATTN_ABLATE & 1)) __syncthreads();
+    __syncthreads();
     mark(5);   // barrier
   }
   if (dbg && tid == 0) {
@@ -880,7 +873,7 @@ inline AttnDev to_dev(const AttnArgs& a) {
   d.mode = a.mode;
   d.Lkr = a.Lk_rows > 0 ? a.Lk_rows : a.Lk;
   d.q_off = a.q_off;
-  d.dbg = g_attn_dbg;
+  d.dbg = a.tune ? a.tune->attn_dbg : nullptr;
   return d;
 }
 
@@ -929,9 +922,7 @@ int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
 }
 
 
-int g_attn4_min_lq = 64;   // queries per (batch, head) from which the 4-wave LDS-shared kernel is used
-void set_attn4_min_lq(int v) { g_attn4_min_lq = v; }
-void set_attn_dbg(long long* p) { g_attn_dbg = p; }
+constexpr int kAttn4MinLq = 64;   // default: queries per (batch, head) from which the 4-wave LDS-shared kernel is used
 
 template <int D, int MODE>
 static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
@@ -954,8 +945,6 @@ static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int g_attn_split = 1;   // use the split-key kernel for Lq <= 32 (cross / short causal attention)
-void set_attn_split(int v) { g_attn_split = v; }
 
 template <int D, int MODE>
 static int launch_split(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
@@ -982,11 +971,13 @@ int launch_attn_mfma(const AttnArgs& a, hipStream_t st) {
   // 16-byte fragment loads: rows and head offsets must be 16-B aligned
   if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) return (int)hipErrorInvalidValue;
   const AttnDev d = to_dev(a);
-  if (g_attn_split && a.Lq <= 32 && a.mode != ATTN_T5 && a.Lk >= 64) {
+  const int use_split = (a.tune && a.tune->attn_split >= 0) ? a.tune->attn_split : 1;   // split-key kernel for Lq <= 32
+  const int min_lq4 = (a.tune && a.tune->attn4_min_lq >= 0) ? a.tune->attn4_min_lq : kAttn4MinLq;
+  if (use_split && a.Lq <= 32 && a.mode != ATTN_T5 && a.Lk >= 64) {
     if (a.D == 32) return a.mode == ATTN_CROSS ? launch_split<32, ATTN_CROSS>(d, a, st) : launch_split<32, ATTN_CAUSAL>(d, a, st);
     return a.mode == ATTN_CROSS ? launch_split<64, ATTN_CROSS>(d, a, st) : launch_split<64, ATTN_CAUSAL>(d, a, st);
   }
-  if (a.Lq >= g_attn4_min_lq) {
+  if (a.Lq >= min_lq4) {
     if (a.D == 32) {
       if (a.mode == ATTN_T5) return launch_mfma4<32, ATTN_T5>(d, a, st);
       if (a.mode == ATTN_CROSS) return launch_mfma4<32, ATTN_CROSS>(d, a, st);

@@ -35,19 +35,10 @@ namespace vima {
 
 namespace {
 
-#ifndef VIMA_GEMM_INTERLEAVE_DMA
-#define VIMA_GEMM_INTERLEAVE_DMA 1
-#endif
-#ifndef VIMA_GEMM_DEPHASE
-#define VIMA_GEMM_DEPHASE 1
-#endif
-#ifndef VIMA_GEMM_ABLATE
-#define VIMA_GEMM_ABLATE 0
-#endif
-// experiment only (wrong results): 1 = no LDS-DMA in the main loop, 2 = no s_barrier, 4 = no fragment ds_reads, 8 = no vmcnt wait, 16 = no MFMAs
-constexpr int kAblate = VIMA_GEMM_ABLATE;
-constexpr bool kDephase = VIMA_GEMM_DEPHASE != 0;   // waves sharing a SIMD prefetch fragments at different points of a step
-constexpr bool kInterleaveDma = VIMA_GEMM_INTERLEAVE_DMA != 0;   // DMA pieces issued between the MFMAs of the last k-step
+// The main-loop ablation builds behind DESIGN.md 4.2 (timing only, wrong results) are NOT part of this source:
+// scripts/ablate/gemm_ablate.patch re-creates them on a scratch copy (scripts/build_ablate.sh).
+constexpr bool kDephase = true;          // waves sharing a SIMD prefetch fragments at different points of a step
+constexpr bool kInterleaveDma = true;    // DMA pieces issued between the MFMAs of the last k-step
 
 template <int BM_, int BN_, int WM_, int WN_, int RB_, int NS_, int MINW_ = 2>
 struct Tile {
@@ -90,20 +81,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // ds_read of every K-slice (it cannot prove the DMA target stage and the stage being read are disjoint), which
 // serialises load and MFMA inside a wave. M0 carries the wave-uniform LDS byte address and is written in the same
 // statement that uses it (hipcc reserves M0 and does not preserve it across statements).
-#ifndef VIMA_GEMM_M0MODE
-#define VIMA_GEMM_M0MODE 0
-#endif
 __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_addr) {
-#if VIMA_GEMM_M0MODE == 0
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-#elif VIMA_GEMM_M0MODE == 1   // experiment: M0 declared clobbered, never restored
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-               :: "v"(gsrc), "s"(lds_byte_addr) : "memory", "m0");
-#else                         // experiment (wrong results): M0 not written at all
-  asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_byte_addr) : "memory");
-#endif
 }
 
 // SADDR form: uniform 64-bit base in SGPRs + per-lane unsigned 32-bit BYTE offset (half the address registers and VALU)
@@ -317,15 +298,13 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   // operands are already in registers). VMEM loads retire in order, so `vmcnt(n * NP)` = "all but the n youngest slices".
   auto wait_slices_and_barrier = [&](int younger) {   // `younger` slices of DMA may stay in flight (wave-uniform)
     if constexpr (ASMLDS) {
-      if constexpr (kAblate & 8) younger = 100;
-      if (younger >= 100) {}
-      else if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
       else if (younger == 2 || NS <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NP) : "memory");
       else if (younger == 3 || NS <= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS > 3 ? 3 * NP : 0) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS > 4 ? 4 * NP : 0) : "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) via the builtin: keeps hipcc's scoreboard exact
-      if constexpr (!(kAblate & 2)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     } else {
       wait_all_and_barrier();
@@ -344,12 +323,6 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   for (int mi = 0; mi < MI; ++mi) fa[0][mi].template load<RB>(smem, arow + mi * 32, 0, hi);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) fw[0][ni].template load<RB>(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
-  if constexpr (kAblate & 4) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) fa[1][mi] = fa[0][mi];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) fw[1][ni] = fw[0][ni];
-  }
   // The two waves that share a SIMD (w and w + NW/2 of an 8-wave workgroup) run the SAME instruction stream in lock
   // step after every barrier; if both fetch fragments at the same moment the matrix pipe idles, then both compete
   // for it. The second half of the waves therefore issues its fragment prefetch in the MIDDLE of each step's MFMAs.
@@ -363,7 +336,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
       for (int mi = mi0; mi < mi1; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          if constexpr (!(kAblate & 16)) acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
+          acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
           if (dma) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -388,12 +361,10 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             mma_block(0, MI / 2, cb, false, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (!(kAblate & 4)) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
+          for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
-          }
+          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
           // pin the order: [ds_reads] then [MFMAs]; without this hipcc re-serialises read -> wait -> 2 MFMAs
           __builtin_amdgcn_sched_barrier(0);
           mma_block(LATE ? MI / 2 : 0, MI, cb, false, 0, 0);
@@ -403,7 +374,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           int last = kt + NS - 1;
           last = last < nk - 1 ? last : nk - 1;
           wait_slices_and_barrier(last - (kt + 1));
-          if (kt + 1 < nk && !(kAblate & 4)) {
+          if (kt + 1 < nk) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(nA, arow + mi * 32, 0, hi);
 #pragma unroll
@@ -411,7 +382,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           }
           __builtin_amdgcn_sched_barrier(0);
           // the DMA pieces of slice kt+NS go into the stage just freed, ONE BY ONE BETWEEN the MFMAs
-          const bool more = kt + NS < nk && !(kAblate & 1);
+          const bool more = kt + NS < nk;
           mma_block(0, MI, cb, more, cur, kt + NS);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -897,32 +868,27 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
   }
 }
 
-// 1 = inline-asm LDS-DMA (default), 0 = compiler-tracked builtin (TileS only). Override with VIMA_GEMM_VARIANT.
-int g_gemm_variant = -1;
-int g_gemm_tile = -1;   // 0 auto, 1 force TileS, 2 force TileL (bf16 only)
-int g_gemm_raster = -1; // see GemmDev::raster
+// Knob resolution: the handle's Tuning value when set (>= 0), otherwise the process default from the environment
+// (read once; never written afterwards, so it is safe to share between handles).
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && e[0]) ? atoi(e) : dflt;
 }
-inline int gemm_variant() {
-  if (g_gemm_variant < 0) g_gemm_variant = env_int("VIMA_GEMM_VARIANT", 1) ? 1 : 0;
-  return g_gemm_variant;
-}
-int g_gemm_epi = -1;
-long long* g_gemm_dbg = nullptr;
 inline int env_cached(const char* name, int& cache, int dflt) {
   if (cache < 0) cache = env_int(name, dflt);
   return cache;
 }
-inline int gemm_raster() {
-  if (g_gemm_raster < 0) g_gemm_raster = env_int("VIMA_GEMM_RASTER", 0);
-  return g_gemm_raster;
-}
-inline int gemm_tile() {
-  if (g_gemm_tile < 0) g_gemm_tile = env_int("VIMA_GEMM_TILE", 0);
-  return g_gemm_tile;
-}
+int g_env_variant = -1, g_env_tile = -1, g_env_raster = -1, g_env_epi = -1, g_env_persist = -1, g_env_small = -1, g_env_splitk = -1;
+#define VIMA_KNOB(fn, field, env, cache, dflt)                                   \
+  inline int fn(const Tuning* t) { return (t && t->field >= 0) ? t->field : env_cached(env, cache, dflt); }
+VIMA_KNOB(gemm_variant, gemm_variant, "VIMA_GEMM_VARIANT", g_env_variant, 1)
+VIMA_KNOB(gemm_tile, gemm_tile, "VIMA_GEMM_TILE", g_env_tile, 0)
+VIMA_KNOB(gemm_raster, gemm_raster, "VIMA_GEMM_RASTER", g_env_raster, 0)
+VIMA_KNOB(gemm_epi, gemm_epi, "VIMA_GEMM_EPI", g_env_epi, 1)
+VIMA_KNOB(gemm_persist, gemm_persist, "VIMA_GEMM_PERSIST", g_env_persist, 1)
+VIMA_KNOB(gemm_small, gemm_small, "VIMA_GEMM_SMALL", g_env_small, 1)
+VIMA_KNOB(gemm_splitk, gemm_splitk, "VIMA_GEMM_SPLITK", g_env_splitk, 0)
+#undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
@@ -944,9 +910,9 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.mtiles = (d.M + TL::BM - 1) / TL::BM;
   d.ntiles = (d.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
-  d.raster = gemm_raster();
-  d.epi_lds = env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1) || a.ssq_out != nullptr;   // the RMS partial sums exist only in the LDS epilogue
-  d.dbg = g_gemm_dbg;
+  d.raster = gemm_raster(a.tune);
+  d.epi_lds = gemm_epi(a.tune) || a.ssq_out != nullptr;   // the RMS partial sums exist only in the LDS epilogue
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
     const long long panel = (long long)TL::BN * a.K * (long long)sizeof(T);
     long long ng = (3LL << 19) / (panel > 0 ? panel : 1);
@@ -965,8 +931,6 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   }
 }
 
-int g_gemm_small = -1;     // 1 (default): 64x64 / 32x64 tiles for underfilled grids; VIMA_GEMM_SMALL / option gemm_small
-int g_gemm_persist = -1;   // 1 (default): large bf16 GEMMs run on the persistent kernel; VIMA_GEMM_PERSIST / option gemm_persist
 int g_num_cu = 0;
 
 template <int ACT, int EPI>
@@ -994,7 +958,7 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.ntiles = (d.N + TileL::BN - 1) / TileL::BN;
   d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
   d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
-  d.dbg = g_gemm_dbg;
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
   // specialised epilogues for the combinations the policy uses; everything else takes the generic instantiation
   int epi = 0;
@@ -1022,12 +986,10 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
 // rounding level) on whether a problem was small enough to be split -- batch-composition and chunking invariance would
 // only hold to bf16 tolerance. Measured gain: 35 -> 25 us at M = 8, K = 3072; nothing at K = 768 (a second launch costs
 // as much as the saved slices); batch-1 step 6.2 -> 5.5 ms. It is therefore OPT-IN (option gemm_splitk / VIMA_GEMM_SPLITK).
-int g_gemm_splitk = -1;
-
 struct SplitPlan { int S; int Ks; };
 inline SplitPlan splitk_plan(const GemmArgs& a, bool is_bf16) {
   SplitPlan p{1, a.K};
-  if (!env_cached("VIMA_GEMM_SPLITK", g_gemm_splitk, 0)) return p;
+  if (!gemm_splitk(a.tune)) return p;
   const int bk = is_bf16 ? 64 : 32;
   if (a.batch > 1 || a.M <= 0 || a.N <= 0 || a.K % bk || a.N % 4 || a.ssq_out || a.rb > 0) return p;
   const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -1087,7 +1049,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (sp.S > 1 && ok4 && a.splitk_ws_bytes >= (size_t)sp.S * MN * sizeof(float) && aligned_to(a.splitk_ws, 16)) {
       GemmArgs p1;
       p1.A = a.A; p1.lda = a.lda; p1.W = a.W; p1.ldw = a.ldw; p1.M = a.M; p1.N = a.N; p1.K = sp.Ks;
-      p1.batch = sp.S; p1.bsA = sp.Ks; p1.bsW = sp.Ks; p1.out32 = a.splitk_ws; p1.ld32 = a.N; p1.bs32 = MN;
+      p1.tune = a.tune; p1.batch = sp.S; p1.bsA = sp.Ks; p1.bsW = sp.Ks; p1.out32 = a.splitk_ws; p1.ld32 = a.N; p1.bs32 = MN;
       if (int e = launch_t<T>(p1, st)) return e;
       const long long work = (long long)a.M * (a.N / 4);
       hipLaunchKernelGGL(gemm_reduce_kernel<T>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a.splitk_ws, sp.S, MN, a.M,
@@ -1122,11 +1084,11 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 160) && waste < 1.15;   // measured: 192 tiles of 256x256 beat 768 of 128x128 by 10-28 %
-    if (gemm_tile() == 1) large = false;
-    if (gemm_tile() >= 2 && gemm_tile() < 7) large = v;
-    if (gemm_tile() >= 7) large = false;
-    if (large && (gemm_tile() == 0 || gemm_tile() == 2) && env_cached("VIMA_GEMM_PERSIST", g_gemm_persist, 1) && a.batch <= 1 &&
-        a.K >= 2 * 64 && gemm_raster() == 0 && env_cached("VIMA_GEMM_EPI", g_gemm_epi, 1) &&
+    if (gemm_tile(a.tune) == 1) large = false;
+    if (gemm_tile(a.tune) >= 2 && gemm_tile(a.tune) < 7) large = v;
+    if (gemm_tile(a.tune) >= 7) large = false;
+    if (large && (gemm_tile(a.tune) == 0 || gemm_tile(a.tune) == 2) && gemm_persist(a.tune) && a.batch <= 1 &&
+        a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
         (long long)a.N * a.ldw * 2 < (1LL << 32)) {
       const int e = launch_persistent(d, a, st);
@@ -1140,14 +1102,14 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     // and spread the problem over more CUs. Every tile shape accumulates K in the same order, so results do not depend
     // on the choice.
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
-    if (v && gemm_tile() == 0 && env_cached("VIMA_GEMM_SMALL", g_gemm_small, 1) && t128 < 128) {
+    if (v && gemm_tile(a.tune) == 0 && gemm_small(a.tune) && t128 < 128) {
       if (a.M <= 32) return launch_tile<T, TileXS, true>(d, a, v, st);
       return launch_tile<T, Tile64, true>(d, a, v, st);
     }
-    if (gemm_tile() == 7 && v) return launch_tile<T, TileXS, true>(d, a, v, st);
-    if (gemm_tile() == 8 && v) return launch_tile<T, Tile64, true>(d, a, v, st);
+    if (gemm_tile(a.tune) == 7 && v) return launch_tile<T, TileXS, true>(d, a, v, st);
+    if (gemm_tile(a.tune) == 8 && v) return launch_tile<T, Tile64, true>(d, a, v, st);
   }
-  if (gemm_variant() == 1) return launch_tile<T, TileS, true>(d, a, v, st);
+  if (gemm_variant(a.tune) == 1) return launch_tile<T, TileS, true>(d, a, v, st);
   return launch_tile<T, TileS, false>(d, a, v, st);
 }
 
@@ -1160,15 +1122,7 @@ size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16) {
   const SplitPlan sp = splitk_plan(a, is_bf16);
   return sp.S > 1 ? (size_t)sp.S * a.M * a.N * sizeof(float) : 0;
 }
-void set_gemm_splitk(int v) { g_gemm_splitk = v; }
-int get_gemm_splitk() { return env_cached("VIMA_GEMM_SPLITK", g_gemm_splitk, 0); }
-void set_gemm_variant(int v) { g_gemm_variant = v; }
-void set_gemm_tile(int v) { g_gemm_tile = v; }
-void set_gemm_raster(int v) { g_gemm_raster = v; }
-void set_gemm_epi(int v) { g_gemm_epi = v; }
-void set_gemm_persist(int v) { g_gemm_persist = v; }
-void set_gemm_small(int v) { g_gemm_small = v; }
-void set_gemm_dbg(long long* p) { g_gemm_dbg = p; }
+int gemm_splitk_enabled(const Tuning* t) { return gemm_splitk(t); }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
 
 }  // namespace vima

@@ -4,6 +4,23 @@
 
 namespace vima {
 
+// Kernel-selection knobs of ONE handle (vima_set_option). -1 = process default (the VIMA_* environment variable named
+// beside each field, read once). They travel with every launch (GemmArgs::tune / AttnArgs::tune): two handles in one
+// process never see each other's settings, and a handle's captured hipGraphs are keyed on its own generation counter.
+struct Tuning {
+  int gemm_variant = -1;   // VIMA_GEMM_VARIANT  1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin (TileS)
+  int gemm_tile = -1;      // VIMA_GEMM_TILE     0 auto, 1 128x128, 2 256x256 8 waves, 7 32x64, 8 64x64
+  int gemm_raster = -1;    // VIMA_GEMM_RASTER   tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
+  int gemm_epi = -1;       // VIMA_GEMM_EPI      1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
+  int gemm_persist = -1;   // VIMA_GEMM_PERSIST  1 = large bf16 GEMMs on the persistent kernel (default)
+  int gemm_small = -1;     // VIMA_GEMM_SMALL    1 = 64x64 / 32x64 tiles for underfilled grids (default)
+  int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
+  long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
+  int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
+  int attn4_min_lq = -1;   // Lq from which the 4-wave LDS-shared flash kernel is used (default 64)
+  long long* attn_dbg = nullptr;   // device buffer [workgroups*8] of phase clocks of the 4-wave kernel (nullptr = off)
+};
+
 // ---------------------------------------------------------------- GEMM
 // C[M,N] = epilogue( A[M,K] . W[N,K]^T ), fp32 accumulation on the matrix cores.
 //   epilogue(v) = ((act(v + bias[n])) * mul[r][n]) + res[r][n]
@@ -42,22 +59,15 @@ struct GemmArgs {
   // gemm_splitk_bytes(). Without it the launch is a single pass.
   float* splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
+  const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
 };
 // returns hipError_t as int; is_bf16 selects the operand type
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
 // Bytes of split-K scratch this problem wants (0: single pass). Deterministic two-pass split-K: pass 1 = the same GEMM
 // kernel over S K-ranges writing fp32 partials, pass 2 = gemm_reduce_kernel (sum in split order + the full epilogue).
 size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
-void set_gemm_splitk(int v);        // 1 = split-K for underfilled grids with K >= 1536, 0 = never (default: results stay independent of the batch size)
-int get_gemm_splitk();
+int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
-void set_gemm_variant(int v);       // 1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin
-void set_gemm_raster(int v);        // tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
-void set_gemm_epi(int v);           // 1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
-void set_gemm_persist(int v);       // 1 = large bf16 GEMMs on the persistent (one workgroup per CU) kernel (default), 0 = one tile per workgroup
-void set_gemm_small(int v);         // 1 = 64x64 / 32x64 tiles for underfilled grids (default), 0 = 128x128 only
-void set_gemm_dbg(long long* p);     // debug: device buffer [blocks*4] of shader-clock stamps (nullptr = off)
-void set_gemm_tile(int v);          // 0 = auto, 1 = 128x128 (TileS), 2 = 256x256 8 waves (TileL; persistent kernel unless gemm_persist=0)
 
 // ---------------------------------------------------------------- normalisation / elementwise
 // LayerNorm (rms=0: mean/var, affine) or T5 RMSNorm (rms=1: no mean, no bias). fp32 statistics.
@@ -124,12 +134,10 @@ struct AttnArgs {
   // rule compares key j with the query's GLOBAL position i + q_off.
   int Lk_rows = 0;
   int q_off = 0;
+  const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
 };
 // generic exact kernel (any T); the MFMA flash kernel (bf16, D in {32,64})
 int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st);
 int launch_attn_mfma(const AttnArgs& a, hipStream_t st);
-void set_attn_split(int v);     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
-void set_attn_dbg(long long* p);  // debug: device buffer [workgroups*8] of accumulated phase clocks of the 4-wave kernel (nullptr = off)
-void set_attn4_min_lq(int v);   // Lq threshold for the 4-wave LDS-shared flash kernel (below: 1-wave kernel)
 
 }  // namespace vima

@@ -135,6 +135,7 @@ struct VimaHandle {
   bool bf16 = true;
   bool finalized = false;
   int attn_impl = 1;
+  Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
   int vit_chunk = 16384;
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
   int t5_fuse_rms = 1;      // T5 RMSNorms folded into the neighbouring GEMMs (statistics in the producer epilogue, row scale in the consumer)
@@ -484,7 +485,8 @@ int pack_all(VimaHandle* h) {
       }
     }
     if (ok) { h->act1_W = P.up_T(w); h->act1_b = P.up_f32(b.data(), b.size()); }
-    h->act_post = P.linear("action_encoder._post_layer", E, 1024, true);
+    // ActionEmbedding._post_layer is nn.Identity when embed_dim == 4 * 256 (action_embd.py:24-27): no such key then
+    if (E != 1024) h->act_post = P.linear("action_encoder._post_layer", E, 1024, true);
   }
   if (!P.missing.empty()) return fail("vima_finalize_params (strict):" + P.missing);
   return 0;
@@ -528,6 +530,7 @@ struct Run {
 
   int gemm(GemmArgs a) {
     if (err) return err;
+    a.tune = &h->tune;
     if (const size_t wsb = gemm_splitk_bytes(a, h->bf16)) {   // underfilled grid: scratch for the two-pass split-K
       a.splitk_ws = ws<float>(wsb / sizeof(float));
       a.splitk_ws_bytes = wsb;
@@ -563,8 +566,9 @@ struct Run {
     if (e) err = fail(std::string(what) + " launch failed: " + hipGetErrorString((hipError_t)e), e);
     return err;
   }
-  int attn(const AttnArgs& a, int impl) {
+  int attn(AttnArgs a, int impl) {
     if (err) return err;
+    a.tune = &h->tune;
     prof_begin(1, 4.0 * a.B * (double)a.H * a.Lq * (double)a.Lk * a.D);
     int e;
     if (impl == 1 && h->bf16 && (a.D == 32 || a.D == 64)) e = launch_attn_mfma(a, st);   // other head dims: exact generic kernel
@@ -831,7 +835,7 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   const long long off1 = (long long)nb[0] * L;      // first row of the second half
   // with the opt-in split-K, small problems keep the standalone RMSNorm: the producer-side statistics are not available
   // from the two-pass split-K, and the norm kernels cost microseconds there
-  const bool fused = h->t5_fuse_rms != 0 && (!get_gemm_splitk() || (long long)nb[0] * L >= 8192);
+  const bool fused = h->t5_fuse_rms != 0 && (!gemm_splitk_enabled(&h->tune) || (long long)nb[0] * L >= 8192);
   const float* ss[2] = {nullptr, nullptr};
   int parts = 1;
   if (fused) {   // entry of the chain: operand-type copy of x and its row sums of squares (one partial per row)
@@ -1079,17 +1083,17 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   drop_graphs(h);
   if (k == "graphs") h->graph_mode = (int)value;
   else if (k == "attn_impl") h->attn_impl = (int)value;
-  else if (k == "gemm_variant") set_gemm_variant((int)value);
-  else if (k == "gemm_tile") set_gemm_tile((int)value);
-  else if (k == "gemm_raster") set_gemm_raster((int)value);
-  else if (k == "gemm_epi") set_gemm_epi((int)value);
-  else if (k == "gemm_persist") set_gemm_persist((int)value);
-  else if (k == "gemm_splitk") set_gemm_splitk((int)value);
-  else if (k == "gemm_small") set_gemm_small((int)value);
-  else if (k == "gemm_dbg_ptr") set_gemm_dbg(reinterpret_cast<long long*>((uintptr_t)value));
-  else if (k == "attn4_min_lq") set_attn4_min_lq((int)value);
-  else if (k == "attn_dbg_ptr") set_attn_dbg(reinterpret_cast<long long*>((uintptr_t)value));
-  else if (k == "attn_split") set_attn_split((int)value);
+  else if (k == "gemm_variant") h->tune.gemm_variant = (int)value;
+  else if (k == "gemm_tile") h->tune.gemm_tile = (int)value;
+  else if (k == "gemm_raster") h->tune.gemm_raster = (int)value;
+  else if (k == "gemm_epi") h->tune.gemm_epi = (int)value;
+  else if (k == "gemm_persist") h->tune.gemm_persist = (int)value;
+  else if (k == "gemm_splitk") h->tune.gemm_splitk = (int)value;
+  else if (k == "gemm_small") h->tune.gemm_small = (int)value;
+  else if (k == "gemm_dbg_ptr") h->tune.gemm_dbg = reinterpret_cast<long long*>((uintptr_t)value);
+  else if (k == "attn4_min_lq") h->tune.attn4_min_lq = (int)value;
+  else if (k == "attn_dbg_ptr") h->tune.attn_dbg = reinterpret_cast<long long*>((uintptr_t)value);
+  else if (k == "attn_split") h->tune.attn_split = (int)value;
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else if (k == "dual_stream") h->dual_stream = (int)value;
@@ -1484,7 +1488,12 @@ int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int Rn, float*
           "action_l1");
   GemmArgs a;
   a.A = t1; a.lda = 1024; a.bsA = 256; a.W = h->act1_W; a.ldw = 256; a.bsW = 256 * 256; a.M = Rn; a.N = 256; a.K = 256; a.batch = 4;
-  a.bias = h->act1_b; a.bsBias = 256; a.outT = t2; a.ldT = 1024; a.bsT = 256;
+  a.bias = h->act1_b; a.bsBias = 256;
+  if (E == 1024) {   // Identity post layer: the concatenated 4 x 256 outputs ARE the token
+    a.out32 = out; a.ld32 = 1024; a.bs32 = 256;
+    return R.gemm(a);
+  }
+  a.outT = t2; a.ldT = 1024; a.bsT = 256;
   R.gemm(a);
   return R.linear(t2, 1024, h->act_post, Rn, ACT_NONE, nullptr, 0, nullptr, 0, out, E, nullptr, 0);
   });

@@ -327,7 +327,15 @@ class VIMAPolicy(nn.Module):
             self._check_input(obs_token, prompt_token, prompt_token_mask, obs_mask)
             self._input_checked = True
         dev = self._device
-        obs_token = obs_token.to(dev).contiguous()
+        # cheap host-side checks on EVERY call (the reference asserts fp32 in _check_input; the raw-pointer boundary would
+        # silently reinterpret any other dtype): shapes + dtypes, no device synchronisation
+        if obs_token.dtype != torch.float32 or prompt_token.dtype != torch.float32:
+            raise AssertionError(f"obs_token / prompt_token must be float32 (xattn_gpt.py:150,152), got {obs_token.dtype} / {prompt_token.dtype}")
+        if prompt_token.dim() != 3 or prompt_token.shape[1] != B or prompt_token.shape[2] != E:
+            raise AssertionError(f"prompt_token must be [Lp, {B}, {E}], got {tuple(prompt_token.shape)}")
+        if tuple(obs_mask.shape) != (L_obs, B, Q) or tuple(prompt_token_mask.shape) != (B, prompt_token.shape[0]):
+            raise AssertionError("obs_mask / prompt_token_mask shapes do not match the tokens")
+        obs_token = obs_token.to(device=dev, dtype=torch.float32).contiguous()
         obs_mask = obs_mask.to(device=dev, dtype=torch.bool).contiguous()
         L_act = 0
         if action_token is not None:
@@ -335,23 +343,48 @@ class VIMAPolicy(nn.Module):
             action_token = action_token.to(device=dev, dtype=torch.float32).contiguous()
         if prompt_token.stride(-1) != 1:
             prompt_token = prompt_token.contiguous()
-        prompt_token = prompt_token.to(dev)
+        prompt_token = prompt_token.to(device=dev, dtype=torch.float32)
         prompt_token_mask = prompt_token_mask.to(device=dev, dtype=torch.bool).contiguous()
         Lp = prompt_token.shape[0]
         out = torch.empty(L_obs, B, E, dtype=torch.float32, device=dev)
         mode = 0
-        if self.cache_prompt_kv:
-            key = (prompt_token.data_ptr(), prompt_token._version, tuple(prompt_token.shape), tuple(prompt_token.stride()),
-                   prompt_token_mask.data_ptr(), prompt_token_mask._version)
+        key = self._prompt_key(prompt_token, prompt_token_mask) if self.cache_prompt_kv else None
+        if key is not None:
             mode = 2 if key == self._kv_key else 1
             self._kv_key = None   # invalid until the call below succeeded
         _lib.check(self._lib.vima_decode(
             self._handle, _ptr(obs_token), _ptr(obs_mask), _ptr(action_token), L_obs, B, Q, L_act, _ptr(prompt_token),
             prompt_token.stride(1), prompt_token.stride(0), _ptr(prompt_token_mask), Lp, mode, _ptr(out), self._stream()))
-        if self.cache_prompt_kv:
+        if key is not None:
             self._kv_key = key
             self._kv_keepalive = (prompt_token, prompt_token_mask)   # the key is only meaningful while these are alive
         return out
+
+    @staticmethod
+    def _prompt_key(prompt_token, prompt_token_mask):
+        """Identity of the prompt for the cross-step K/V cache: storage pointer, in-place version counter, layout.
+        Inference tensors (created under torch.inference_mode()) do not track a version counter: no key -> the call is
+        stateless (mode 0), exactly like the reference."""
+        if prompt_token.is_inference() or prompt_token_mask.is_inference():
+            return None
+        try:
+            return (prompt_token.data_ptr(), prompt_token._version, tuple(prompt_token.shape), tuple(prompt_token.stride()),
+                    prompt_token_mask.data_ptr(), prompt_token_mask._version)
+        except RuntimeError:
+            return None
+
+    def reset_prompt_cache(self):
+        """Forget the cached per-layer prompt K/V. CONTRACT of the default-on cache (`cache_prompt_kv`): `forward` reuses
+        the K/V projections of the previous call when it is handed the same prompt tensor object state (same storage,
+        same torch version counter, same layout). Writers that bypass the version counter (`.data.copy_`, DLPack / raw
+        pointer writers, external kernels) must call this -- or start every episode with it -- otherwise stale K/V would
+        be used. Set `policy.cache_prompt_kv = False` for the reference's stateless behaviour."""
+        self._kv_key = None
+        self._kv_keepalive = None
+
+    def new_episode(self):
+        """Episode-start hook: drops the prompt K/V cache (see reset_prompt_cache)."""
+        self.reset_prompt_cache()
 
     def forward_step(self, obs_token: torch.Tensor, obs_mask: torch.Tensor, prev_action_token: torch.Tensor | None,
                      prompt_token: torch.Tensor, prompt_token_mask: torch.Tensor, step: int):

@@ -186,7 +186,8 @@ def make_state_dict(cfg: PolicyConfig, seed: int = 0, head_gain: float = 0.01) -
     for k in ACTION_KEYS:
         in_dim = 2 if k.endswith("position") else 4
         I.mlp(f"action_encoder._embed_dict.{k}._layer", [in_dim, 256, 256])
-    I.linear("action_encoder._post_layer", E, 1024, 1024 ** -0.5 * 0.58)
+    if E != 1024:   # nn.Identity when embed_dim == 4 * 256 (action_embd.py:16-20)
+        I.linear("action_encoder._post_layer", E, 1024, 1024 ** -0.5 * 0.58)
     # ---- action decoder (action_decoder.py:128-166) ----
     for k in ACTION_KEYS:
         for j, bins in enumerate(ACTION_DIMS[k]):
