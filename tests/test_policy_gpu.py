@@ -388,13 +388,17 @@ def test_options_are_per_handle():
     otok = torch.randn(1, B, Q, E, generator=g).to(DEV)
     omask = torch.ones(1, B, Q, dtype=torch.bool, device=DEV)
     a = loaded_policy(cfg, sd, "fp32", graphs=1)
-    base = [a.forward(otok, omask, None, ptok, pmask).clone() for _ in range(3)]       # eager, capture, replay
+    b = loaded_policy(cfg, sd, "fp32")
+    b.forward(otok, omask, None, ptok, pmask)
+    base = [a.forward(otok, omask, None, ptok, pmask).clone() for _ in range(5)]   # eager (cache build), eager, capture, replay, replay
     r0, c0 = a.graph_stats()
-    b = loaded_policy(cfg, sd, "fp32", attn_impl=0, gemm_tile=1, gemm_variant=0, gemm_epi=0, attn_split=0, gemm_splitk=1)
-    other = b.forward(otok, omask, None, ptok, pmask)
-    again = a.forward(otok, omask, None, ptok, pmask)
+    assert c0 >= 1 and r0 >= 1
+    for k, v in dict(attn_impl=0, gemm_tile=1, gemm_variant=0, gemm_epi=0, attn_split=0, gemm_splitk=1).items():
+        b.set_option(k, v)                                   # options of B change AFTER A captured its graph
+    other = b.forward(otok, omask, None, ptok, pmask).clone()
+    again = a.forward(otok, omask, None, ptok, pmask).clone()
     r1, c1 = a.graph_stats()
-    assert torch.equal(again, base[0]) and torch.equal(base[1], base[0]) and torch.equal(base[2], base[0])
+    assert all(torch.equal(x, base[0]) for x in base) and torch.equal(again, base[0])
     assert c1 == c0 and r1 == r0 + 1, "policy A's captured graph must survive option changes on policy B"
     assert max_abs(other, again) < 1e-4
 
