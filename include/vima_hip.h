@@ -121,6 +121,18 @@ int vima_action_head(VimaHandle* h, const float* tokens, int R, float* out_logit
  * pose1_rotation [R,4] -> out f32 [R,E]. */
 int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int R, float* out, vima_stream_t stream);
 
+/* ---- image preprocessing in front of the policy ------------------------------------------- */
+/* The per-object work of prepare_obs / prepare_prompt (/root/reference/scripts/example.py:374-473 and :243-371; numpy +
+ * cv2 per object on the host there): for every frame and every object id, segmentation mask -> pixel bbox ->
+ * inclusive crop -> zero-pad to a square -> cv2.resize(32x32, INTER_AREA) -> uint8, with the reference's slot order
+ * (objects covering >= 2 pixels first, in obj_ids order; the rest zero rows with mask 0).
+ * rgb u8 [n_frames,3,H,W], segm [n_frames,H,W] of uint8 (segm_elem_bytes 1) or int32 (4), obj_ids i32 [n_obj <= 64]
+ * (all device pointers; H, W <= 320) -> crops u8 [n_frames,n_obj,3,32,32], bbox i64 [n_frames,n_obj,4] = (int x-centre,
+ * int y-centre, ymax-ymin, xmax-xmin), mask u8 [n_frames,n_obj]: exactly the cropped_img / bbox / mask arrays of ONE view
+ * that vima_obs_encode / vima_prompt_encode take. No handle: there are no weights involved. */
+int vima_crop_objects(const uint8_t* rgb, const void* segm, int segm_elem_bytes, const int32_t* obj_ids, int n_frames,
+                      int n_obj, int H, int W, uint8_t* crops, int64_t* bbox, uint8_t* mask, vima_stream_t stream);
+
 /* ---- multi-GPU: the one exchange step of the data-parallel path ----------------------------------- */
 /* The reference has no distributed code (no torch.distributed / NCCL call site anywhere under vima/); batched episodes
  * are independent, so the path shards over one process per GPU with a full weight replica and ONE collective per

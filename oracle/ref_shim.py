@@ -67,8 +67,9 @@ def load_reference():
         def map_structure(func, *structs):
             """Minimal dm-tree `map_structure` (dict / list / tuple nests) for vima/utils.py any_* helpers."""
             s0 = structs[0]
-            if isinstance(s0, dict):
-                return type(s0)({k: map_structure(func, *[s[k] for s in structs]) for k in s0})
+            import collections.abc as cabc
+            if isinstance(s0, cabc.Mapping):
+                return type(s0)({k: map_structure(func, *[s[k] for s in structs]) for k in s0.keys()})
             if isinstance(s0, (list, tuple)):
                 return type(s0)(map_structure(func, *xs) for xs in zip(*structs))
             return func(*structs)
@@ -94,6 +95,42 @@ def load_reference():
             return structure
 
         tree.traverse = traverse
+
+        def _is_map(x):
+            import collections.abc as cabc
+            return isinstance(x, cabc.Mapping)
+
+        def map_structure_with_path(func, *structs, _path=()):
+            s0 = structs[0]
+            if _is_map(s0):
+                return type(s0)({k: map_structure_with_path(func, *[s[k] for s in structs], _path=_path + (k,)) for k in s0.keys()})
+            if isinstance(s0, (list, tuple)):
+                return type(s0)(map_structure_with_path(func, *xs, _path=_path + (i,)) for i, xs in enumerate(zip(*structs)))
+            return func(_path, *structs)
+
+        def flatten(structure):
+            """dm-tree order: mappings by sorted key, sequences in order."""
+            if _is_map(structure):
+                return [leaf for k in sorted(structure.keys()) for leaf in flatten(structure[k])]
+            if isinstance(structure, (list, tuple)):
+                return [leaf for v in structure for leaf in flatten(v)]
+            return [structure]
+
+        def unflatten_as(structure, flat):
+            it = iter(flat)
+
+            def rec(s):
+                if _is_map(s):
+                    vals = {k: rec(s[k]) for k in sorted(s.keys())}
+                    return type(s)({k: vals[k] for k in s.keys()})
+                if isinstance(s, (list, tuple)):
+                    return type(s)(rec(v) for v in s)
+                return next(it)
+            return rec(structure)
+
+        tree.map_structure_with_path = map_structure_with_path
+        tree.flatten = flatten
+        tree.unflatten_as = unflatten_as
     import transformers.models.t5.modeling_t5 as mt5
     from transformers import T5Config
 

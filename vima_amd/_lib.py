@@ -55,6 +55,8 @@ PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_double)]),
     "vima_workspace_bytes": (c_i64, [vp]),
     "vima_graph_stats": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "vima_crop_objects": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
+                                         vp, vp]),
     "vima_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "vima_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
     "vima_comm_world": (ctypes.c_int, [vp]),
