@@ -86,3 +86,26 @@ def test_embed_dim_1024_has_no_action_post_layer():
     assert "t5_prompt_encoder_post_layer.weight" in req
     sd = syn.make_state_dict(cfg, 0)
     assert set(req) <= set(sd) and not (set(sd) - set(req) - set(ign))
+
+
+def test_fp8_e4m3_encoder_matches_torch():
+    """The host-side fp32 -> OCP FP8 E4M3 encoder of the fp8w weight packing against torch.float8_e4m3fn (round to nearest
+    even; torch does not saturate finite overflow to 448 -> compared inside the finite range, saturation checked apart)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(20000, generator=g) * s for s in (1e-3, 0.02, 1.0, 50.0, 200.0)])
+    x = torch.cat([x, torch.tensor([0.0, -0.0, 448.0, -448.0, 0.015625, 0.001953125, 0.0009765625, 0.0029296875, 447.9, 463.9,
+                                    2 ** -6 * 0.9999, 1.0625, 1.1875, 0.5 + 1 / 32])])
+    x = x[x.abs() < 464].contiguous()
+    out = torch.empty(x.numel(), dtype=torch.uint8)
+    lib.vima_fp8_e4m3_encode(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), x.numel())
+    want = x.to(torch.float8_e4m3fn).view(torch.uint8)
+    same = (out == want) | ((out & 0x7f) == 0) & ((want & 0x7f) == 0)          # +-0 may differ in sign bit conventions
+    assert bool(same.all()), (x[~same][:5], out[~same][:5], want[~same][:5])
+    big = torch.tensor([464.0, 1e4, -1e9, float("inf")])
+    o2 = torch.empty(4, dtype=torch.uint8)
+    lib.vima_fp8_e4m3_encode(ctypes.c_void_p(big.data_ptr()), ctypes.c_void_p(o2.data_ptr()), 4)
+    assert o2.tolist() == [0x7e, 0x7e, 0xfe, 0x7e]                                 # saturate to +-448
+    back = out.view(torch.float8_e4m3fn).float()
+    rel = ((back - x).abs() / x.abs().clamp_min(2 ** -6)).max().item()
+    assert rel <= 2 ** -4 + 1e-6                                                    # 3 mantissa bits: half an ulp = 1/16

@@ -21,7 +21,7 @@ class VimaConfig(ctypes.Structure):
                                      "xattn_n_positions", "n_positions", "precision")]
 
 
-PRECISION = {"fp32": 0, "bf16": 1}
+PRECISION = {"fp32": 0, "bf16": 1, "fp8w": 2}
 
 # exported symbol -> (restype, argtypes); must list every function declared in include/vima_hip.h
 PROTOTYPES = {
@@ -49,6 +49,7 @@ PROTOTYPES = {
     "vima_op_attention": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, c_f32, ctypes.c_int, ctypes.c_int, vp, vp]),
     "vima_t5_bucket": (ctypes.c_int, [ctypes.c_int]),
+    "vima_fp8_e4m3_encode": (None, [vp, vp, c_i64]),
     "vima_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, c_i64]),
     "vima_prof_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "vima_prof_read": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),

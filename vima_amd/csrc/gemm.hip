@@ -111,9 +111,31 @@ template <> struct Frag<bf16_t> {
     const int c = kk * 2 + hi;
     v = *reinterpret_cast<const uint4*>(tile + r * RB + ((c ^ swz<RB>(r)) << 4));
   }
+  // W operand: bf16 rows like A (W8 = false), or FP8 e4m3 rows of RBW = 64 bytes per 64-element K-slice (W8 = true): the
+  // lane's 8 consecutive k of step kk are 8 BYTES at chunk kk (16 B = both lane halves), half `hi`; they are widened
+  // to bf16 in registers (v_cvt_pk_f32_fp8 + v_perm_b32: exact, every e4m3 value is a bf16 value) so that the matrix
+  // instruction and everything behind it stay the bf16 path. 8 VALU ops per fragment beside 8 MFMAs per k-step.
+  template <int RBW, bool W8> __device__ __forceinline__ void loadw(const char* tile, int r, int kk, int hi) {
+    if constexpr (!W8) {
+      load<RBW>(tile, r, kk, hi);
+    } else {
+      typedef __attribute__((ext_vector_type(2))) float f2_t;
+      const uint2 u = *reinterpret_cast<const uint2*>(tile + r * RBW + ((kk ^ swz<RBW>(r)) << 4) + hi * 8);
+      const f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)u.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)u.x, true);
+      const f2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)u.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)u.y, true);
+      v.x = __builtin_amdgcn_perm(__float_as_uint(a.y), __float_as_uint(a.x), 0x07060302u);   // high halves: (bf16(a.x), bf16(a.y))
+      v.y = __builtin_amdgcn_perm(__float_as_uint(b.y), __float_as_uint(b.x), 0x07060302u);
+      v.z = __builtin_amdgcn_perm(__float_as_uint(c.y), __float_as_uint(c.x), 0x07060302u);
+      v.w = __builtin_amdgcn_perm(__float_as_uint(d.y), __float_as_uint(d.x), 0x07060302u);
+    }
+  }
 };
 template <> struct Frag<float> {
   float4 v0, v1;
+  template <int RBW, bool W8> __device__ __forceinline__ void loadw(const char* tile, int r, int kk, int hi) {
+    static_assert(!W8, "fp8 weights exist for the bf16 path only");
+    load<RBW>(tile, r, kk, hi);
+  }
   template <int RB> __device__ __forceinline__ void load(const char* tile, int r, int kk, int hi) {
     static_assert(RB == 128, "fp32 operands use 128-byte K-slices");
     const int c = kk * 4 + hi * 2;
@@ -174,6 +196,7 @@ struct GemmDev {
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
   float* ssq_out; const float* rs_ssq; int rs_parts; float rs_invk, rs_eps;
+  const float* wscale;   // fp8 weights: per-output-channel dequantisation scale [N], applied to the accumulator column
   int mtiles, ntiles;
   int vtotal;   // persistent kernel: number of virtual tile ids = ceil8(mtiles) * ntiles
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
@@ -184,10 +207,14 @@ struct GemmDev {
 };
 
 // ACT >= 0: compile-time activation; ACT == -1: runtime p.act. VEC: 4-wide vector epilogue. ASMLDS: inline-asm LDS-DMA.
-template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS>
+template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS, bool W8 = false>
 __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TL::RB, NS = TL::NS, CPR = TL::CPR;
+  // W operand geometry: bf16 / fp32 rows like A, or fp8 rows of half the bytes (half the LDS-DMA pieces per K-slice)
+  constexpr int RBW = W8 ? RB / 2 : RB, CPRW = RBW / 16, PWN = W8 ? TL::PW / 2 : TL::PW;
+  constexpr int ESW = W8 ? 1 : (int)sizeof(T);
+  static_assert(!W8 || (sizeof(T) == 2 && ASMLDS && VEC && TL::PW % 2 == 0), "fp8 weights: bf16 path, asm LDS-DMA, vector epilogue");
   constexpr int BK = RB / (int)sizeof(T);
   constexpr int EPC = KCfg<T>::EPC;
   constexpr int KSTEPS = BK / 16;
@@ -228,7 +255,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   const int m0 = tm * TL::BM, n0 = tn * TL::BN;
 
   const T* A = reinterpret_cast<const T*>(p.A) + (long long)z * p.bsA;
-  const T* W = reinterpret_cast<const T*>(p.W) + (long long)z * p.bsW;
+  const char* W = reinterpret_cast<const char*>(p.W) + (long long)z * p.bsW * ESW;
   // 8 slots per workgroup: 0-3 shader-clock stamps, 4/5 constant-rate (100 MHz) real-time at start/end, 6 HW_ID, 7 XCC_ID
   auto stamp = [&](int slot) {
     if (p.dbg && tid == 0) {
@@ -246,7 +273,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 
   // per-lane source pointers of this wave's LDS-DMA pieces of one K-slice (piece = 1 KiB = 1024/RB tile rows)
   const T* srcA[TL::PA];
-  const T* srcW[TL::PW];
+  const char* srcW[PWN];
 #pragma unroll
   for (int i = 0; i < TL::PA; ++i) {
     const int s = (i * NW + w) * 64 + lane;
@@ -256,12 +283,12 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
     srcA[i] = A + (long long)ra * p.lda + c * EPC;
   }
 #pragma unroll
-  for (int i = 0; i < TL::PW; ++i) {
+  for (int i = 0; i < PWN; ++i) {
     const int s = (i * NW + w) * 64 + lane;
-    const int r = s / CPR, pp = s % CPR;
-    const int c = pp ^ swz<RB>(r);
+    const int r = s / CPRW, pp = s % CPRW;
+    const int c = pp ^ swz<RBW>(r);
     int rw = n0 + r; rw = rw < p.N ? rw : p.N - 1;
-    srcW[i] = W + (long long)rw * p.ldw + c * EPC;
+    srcW[i] = W + ((long long)rw * p.ldw) * ESW + c * 16;
   }
 
   f32x16_t acc[MI][NI];
@@ -279,11 +306,11 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   // one 1-KiB LDS-DMA piece j of K-slice kt into `stage` (j < PA: A tile rows, else W tile rows)
-  constexpr int NP = TL::PA + TL::PW;
+  constexpr int NP = TL::PA + PWN;
   auto issue_piece = [&](int stage, int kt, int j) {
     const int i = j < TL::PA ? j : j - TL::PA;
     const int off = stage * TL::STAGE_BYTES + (j < TL::PA ? 0 : TL::A_BYTES) + (i * NW + w) * 1024;
-    const T* src = (j < TL::PA ? srcA[i] : srcW[i]) + kt * BK;
+    const void* src = j < TL::PA ? (const void*)(srcA[i] + kt * BK) : (const void*)(srcW[i] + kt * RBW);
     if constexpr (ASMLDS) glds16_asm(src, smem_base + off);
     else glds16(src, smem + off);
   };
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) fa[0][mi].template load<RB>(smem, arow + mi * 32, 0, hi);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) fw[0][ni].template load<RB>(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
+  for (int ni = 0; ni < NI; ++ni) fw[0][ni].template loadw<RBW, W8>(smem + TL::A_BYTES, wrow + ni * 32, 0, hi);
   // The two waves that share a SIMD (w and w + NW/2 of an 8-wave workgroup) run the SAME instruction stream in lock
   // step after every barrier; if both fetch fragments at the same moment the matrix pipe idles, then both compete
   // for it. The second half of the waves therefore issues its fragment prefetch in the MIDDLE of each step's MFMAs.
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
+          for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template loadw<RBW, W8>(sW, wrow + ni * 32, kk + 1, hi);
           // pin the order: [ds_reads] then [MFMAs]; without this hipcc re-serialises read -> wait -> 2 MFMAs
           __builtin_amdgcn_sched_barrier(0);
           mma_block(LATE ? MI / 2 : 0, MI, cb, false, 0, 0);
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(nA, arow + mi * 32, 0, hi);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(nW, wrow + ni * 32, 0, hi);
+            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template loadw<RBW, W8>(nW, wrow + ni * 32, 0, hi);
           }
           __builtin_amdgcn_sched_barrier(0);
           // the DMA pieces of slice kt+NS go into the stage just freed, ONE BY ONE BETWEEN the MFMAs
@@ -435,6 +462,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             const int nl = ni * 32 + 8 * q + 4 * hi;
             float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
             const int nb = n0 + wn * WCOLS + nl;
+            if (p.wscale && nb < p.N) { const float4 sc = load4(p.wscale + nb); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
             if (bias && nb < p.N) { const float4 b = load4(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
             *reinterpret_cast<float4*>(stage + l31 * LDE + nl) = v;
@@ -516,6 +544,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           for (int e = 0; e < 4; ++e) v[e] *= rsc;
         }
         if constexpr (VEC) {   // N % 4 == 0 => n + 3 < N
+          if (p.wscale) { const float4 sc = load4(p.wscale + n); v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w; }
           if (bias) { const float4 b = load4(bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
           if (act != ACT_NONE) {
 #pragma unroll
@@ -557,17 +586,19 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // EPI specialises the epilogue at compile time (fewer live scalars / registers than the all-runtime form, which spilled):
 //   (0 = every feature a runtime flag: not instantiated) 1 bf16-only output, optional bias / fused-RMSNorm row scale
 //   2 bf16-only output x gate (`mul`: GEGLU)      3 residual add with fp32 (+ optional bf16) output, optional RMS partials
-template <int ACT, int EPI>
+template <int ACT, int EPI, bool W8 = false>
 __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(const GemmDev p) {
   using T = bf16_t;
   using TL = TileL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TL::RB, NS = TL::NS, CPR = TL::CPR;
   constexpr int BK = RB / (int)sizeof(T), EPC = KCfg<T>::EPC, KSTEPS = BK / 16;
-  constexpr int MI = TL::MI, NI = TL::NI, NW = TL::NW, NP = TL::PA + TL::PW;
+  // W8: fp8 e4m3 weight rows (64 B per K-slice, half the LDS-DMA pieces), widened to bf16 in registers (Frag::loadw)
+  constexpr int RBW = W8 ? RB / 2 : RB, CPRW = RBW / 16, PWN = W8 ? TL::PW / 2 : TL::PW, ESW = W8 ? 1 : (int)sizeof(T);
+  constexpr int MI = TL::MI, NI = TL::NI, NW = TL::NW, NP = TL::PA + PWN;
   constexpr int EPI_OFF = NS * TL::STAGE_BYTES;     // epilogue slabs live behind the ring: NW x 4 KiB
   static_assert(NS == 2 && RB == 128 && NI == 2 && MI == 4 && NW == 8, "written for TileL");
-  static_assert(NP == MI * NI, "one LDS-DMA piece per MFMA of the last k-step");
+  static_assert(NP <= MI * NI, "at most one LDS-DMA piece per MFMA of the last k-step");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
   const int G = gridDim.x;
   const int nk = p.K / BK;
   const T* A = reinterpret_cast<const T*>(p.A);
-  const T* W = reinterpret_cast<const T*>(p.W);
+  const char* W = reinterpret_cast<const char*>(p.W);
 
   // virtual tile id v -> (tm, tn): workgroup b only ever takes v = b, b + G, ... (G % 8 == 0), so v & 7 is its XCD and
   // one XCD walks the n-tiles of one A panel back to back, as in the one-tile-per-workgroup kernel
@@ -600,10 +631,12 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
   // per-lane BYTE offsets from A / W (SADDR-form LDS-DMA: uniform 64-bit base + unsigned 32-bit lane offset; the
   // launcher guarantees they fit); the k-slice offset is added at issue. The launcher only sends problems with
   // M % 256 == 0 and N % 256 == 0 here, so no row needs clamping.
-  unsigned offA[TL::PA], offW[TL::PW];
+  unsigned offA[TL::PA], offW[PWN];
   int iv, ikt = 0;
   const int r0 = (w * 64 + lane) / CPR;                 // row of this lane within a 64-row piece group
   const int c0 = ((lane % CPR) ^ swz<RB>(r0)) * 16;     // swizzled 16-B chunk (the same for every piece: swz ignores r / 64)
+  const int r0w = (w * 64 + lane) / CPRW;               // the same for the W tile (128-row piece groups when its rows are 64 B)
+  const int c0w = ((lane % CPRW) ^ swz<RBW>(r0w)) * 16;
   auto set_ptrs = [&](int v) {
     int tm, tn;
     tile_at(v, tm, tn);
@@ -611,16 +644,15 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     for (int i = 0; i < TL::PA; ++i)
       offA[i] = (unsigned)(tm * TL::BM + i * (NW * 64 / CPR) + r0) * (unsigned)(p.lda * (int)sizeof(T)) + c0;
 #pragma unroll
-    for (int i = 0; i < TL::PW; ++i)
-      offW[i] = (unsigned)(tn * TL::BN + i * (NW * 64 / CPR) + r0) * (unsigned)(p.ldw * (int)sizeof(T)) + c0;
+    for (int i = 0; i < PWN; ++i)
+      offW[i] = (unsigned)(tn * TL::BN + i * (NW * 64 / CPRW) + r0w) * (unsigned)(p.ldw * ESW) + c0w;
   };
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto issue_piece = [&](int stage, int j) {
     const int i = j < TL::PA ? j : j - TL::PA;
     const int off = stage * TL::STAGE_BYTES + (j < TL::PA ? 0 : TL::A_BYTES) + (i * NW + w) * 1024;
-    const unsigned koff = (unsigned)(ikt * RB);
-    if (j < TL::PA) glds16_asm_s(A, offA[i] + koff, smem_base + off);
-    else glds16_asm_s(W, offW[i] + koff, smem_base + off);
+    if (j < TL::PA) glds16_asm_s(A, offA[i] + (unsigned)(ikt * RB), smem_base + off);
+    else glds16_asm_s(W, offW[i] + (unsigned)(ikt * RBW), smem_base + off);
   };
   auto advance_issue = [&]() {   // after the last piece of a slice
     if (++ikt == nk) {
@@ -691,7 +723,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) fa[0][mi].template load<RB>(sA, arow + mi * 32, 0, hi);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fw[0][ni].template load<RB>(sA + TL::A_BYTES, wrow + ni * 32, 0, hi);
+      for (int ni = 0; ni < NI; ++ni) fw[0][ni].template loadw<RBW, W8>(sA + TL::A_BYTES, wrow + ni * 32, 0, hi);
     }
     stamp(1);
     auto main_loop = [&](auto late_tag) {
@@ -717,7 +749,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(sA, arow + mi * 32, kk + 1, hi);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(sW, wrow + ni * 32, kk + 1, hi);
+            for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template loadw<RBW, W8>(sW, wrow + ni * 32, kk + 1, hi);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = (LATE ? MI / 2 : 0); mi < MI; ++mi)
@@ -735,7 +767,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) fa[nb][mi].template load<RB>(nA, arow + mi * 32, 0, hi);
 #pragma unroll
-              for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template load<RB>(nW, wrow + ni * 32, 0, hi);
+              for (int ni = 0; ni < NI; ++ni) fw[nb][ni].template loadw<RBW, W8>(nW, wrow + ni * 32, 0, hi);
             }
             __builtin_amdgcn_sched_barrier(0);
             const bool more = iv >= 0;   // wave-uniform: the stream has another slice (this tile's or a later tile's)
@@ -745,7 +777,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
               for (int ni = 0; ni < NI; ++ni) {
                 acc[mi][ni] = mma(fw[cb][ni], fa[cb][mi], acc[mi][ni]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_piece(cur, mi * NI + ni);
+                if (more && mi * NI + ni < NP) issue_piece(cur, mi * NI + ni);
                 __builtin_amdgcn_sched_barrier(0);
               }
             if (more) advance_issue();
@@ -788,6 +820,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
         for (int q = 0; q < 4; ++q) {
           float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
           const int nb = nbase + 8 * q + 4 * ehi;
+          if (W8) { const float4 sc = load4(p.wscale + nb); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }   // per-output-channel dequantisation
           if (p.bias && nb < p.N) { const float4 b = load4(p.bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
           if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
           *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
@@ -892,16 +925,16 @@ VIMA_KNOB(gemm_splitk, gemm_splitk, "VIMA_GEMM_SPLITK", g_env_splitk, 0)
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS>
+template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS, bool W8 = false>
 int launch_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TL, ACT, VEC, ASMLDS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TL, ACT, VEC, ASMLDS, W8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM_ALLOC);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, TL, ACT, VEC, ASMLDS>), grid, dim3(TL::THREADS), TL::SMEM_ALLOC, st, d);
+  hipLaunchKernelGGL((gemm_kernel<T, TL, ACT, VEC, ASMLDS, W8>), grid, dim3(TL::THREADS), TL::SMEM_ALLOC, st, d);
   return (int)hipGetLastError();
 }
 
@@ -921,6 +954,17 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
     d.ngroup = (int)ng;
   }
   dim3 grid((unsigned)(d.raster == 2 ? d.mtiles * d.ntiles : groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  if constexpr (sizeof(T) == 2) {
+    if (a.w8) {   // fp8 weights: always the asm LDS-DMA pipeline and the vector epilogue (checked by launch_t)
+      switch (a.act) {
+        case ACT_NONE: return launch_inst<T, TL, ACT_NONE, true, true, true>(d, grid, st);
+        case ACT_RELU: return launch_inst<T, TL, ACT_RELU, true, true, true>(d, grid, st);
+        case ACT_GELU: return launch_inst<T, TL, ACT_GELU, true, true, true>(d, grid, st);
+        case ACT_QUICKGELU: return launch_inst<T, TL, ACT_QUICKGELU, true, true, true>(d, grid, st);
+        default: return (int)hipErrorInvalidValue;
+      }
+    }
+  }
   if (!vec) return launch_inst<T, TL, -1, false, ASMLDS>(d, grid, st);
   switch (a.act) {
     case ACT_NONE: return launch_inst<T, TL, ACT_NONE, true, ASMLDS>(d, grid, st);
@@ -933,18 +977,22 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
 
 int g_num_cu = 0;
 
-template <int ACT, int EPI>
-int launch_persistent_inst(const GemmDev& d, int grid, hipStream_t st) {
+template <int ACT, int EPI, bool W8>
+int launch_persistent_w(const GemmDev& d, int grid, hipStream_t st) {
   constexpr int SMEM = TileL::SMEM_BYTES + TileL::NW * 4096;   // ring + epilogue slabs = 160 KiB
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT, EPI, W8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_persistent_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
+  hipLaunchKernelGGL((gemm_persistent_kernel<ACT, EPI, W8>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
   return (int)hipGetLastError();
+}
+template <int ACT, int EPI>
+int launch_persistent_inst(const GemmDev& d, int grid, hipStream_t st) {
+  return d.wscale ? launch_persistent_w<ACT, EPI, true>(d, grid, st) : launch_persistent_w<ACT, EPI, false>(d, grid, st);
 }
 
 int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
@@ -989,7 +1037,7 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
 struct SplitPlan { int S; int Ks; };
 inline SplitPlan splitk_plan(const GemmArgs& a, bool is_bf16) {
   SplitPlan p{1, a.K};
-  if (!gemm_splitk(a.tune)) return p;
+  if (!gemm_splitk(a.tune) || a.w8) return p;
   const int bk = is_bf16 ? 64 : 32;
   if (a.batch > 1 || a.M <= 0 || a.N <= 0 || a.K % bk || a.N % 4 || a.ssq_out || a.rb > 0) return p;
   const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -1037,8 +1085,11 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.K <= 0 || a.K % BK != 0) return (int)hipErrorInvalidValue;
   // LDS-DMA reads 16-B chunks: rows must start 16-B aligned
   const size_t es = sizeof(T);
-  if (!aligned_to(a.A, 16) || !aligned_to(a.W, 16) || (a.lda * es) % 16 || (a.ldw * es) % 16 ||
-      (a.bsA * es) % 16 || (a.bsW * es) % 16)
+  const size_t esw = a.w8 ? 1 : es;   // fp8 weights: ldw / bsW count bytes
+  if (a.w8 && (sizeof(T) != 2 || !a.wscale || a.N % 4 != 0 || a.K % 64 != 0 || a.batch > 1 || !aligned_to(a.wscale, 16)))
+    return (int)hipErrorInvalidValue;
+  if (!aligned_to(a.A, 16) || !aligned_to(a.W, 16) || (a.lda * es) % 16 || (a.ldw * esw) % 16 ||
+      (a.bsA * es) % 16 || (a.bsW * esw) % 16)
     return (int)hipErrorInvalidValue;
   if (a.splitk_ws) {   // underfilled grid: two deterministic passes (see splitk_plan)
     const SplitPlan sp = splitk_plan(a, sizeof(T) == 2);
@@ -1065,6 +1116,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
+  d.wscale = a.w8 ? a.wscale : nullptr;
   if (a.ssq_out && (!a.out32 || a.batch > 1 || a.N % 32 != 0)) return (int)hipErrorInvalidValue;
   if (a.rs_ssq && a.rs_parts <= 0) return (int)hipErrorInvalidValue;
   d.mtiles = d.ntiles = 0;
@@ -1074,6 +1126,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.res) v = v && aligned_to(a.res, 16) && (a.ldres % 4 == 0) && (a.bsRes % 4 == 0);
   if (a.out32) v = v && aligned_to(a.out32, 16) && (a.ld32 % 4 == 0) && (a.bs32 % 4 == 0);
   if (a.outT) v = v && aligned_to(a.outT, 4 * es) && (a.ldT % 4 == 0) && (a.bsT % 4 == 0);
+  if (a.w8 && !v) return (int)hipErrorInvalidValue;   // fp8 weights need the vector epilogue (16-byte aligned outputs)
   d.wide8 = 0;
   if constexpr (sizeof(T) == 2) {
     d.wide8 = (v && a.outT && !a.out32 && a.N % 8 == 0 && a.ldT % 8 == 0 && a.bsT % 8 == 0 && aligned_to(a.outT, 16) &&
@@ -1090,7 +1143,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (large && (gemm_tile(a.tune) == 0 || gemm_tile(a.tune) == 2) && gemm_persist(a.tune) && a.batch <= 1 &&
         a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
-        (long long)a.N * a.ldw * 2 < (1LL << 32)) {
+        (long long)a.N * a.ldw * (long long)esw < (1LL << 32)) {
       const int e = launch_persistent(d, a, st);
       if (e >= 0) return e;
     }
@@ -1109,7 +1162,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (gemm_tile(a.tune) == 7 && v) return launch_tile<T, TileXS, true>(d, a, v, st);
     if (gemm_tile(a.tune) == 8 && v) return launch_tile<T, Tile64, true>(d, a, v, st);
   }
-  if (gemm_variant(a.tune) == 1) return launch_tile<T, TileS, true>(d, a, v, st);
+  if (gemm_variant(a.tune) == 1 || a.w8) return launch_tile<T, TileS, true>(d, a, v, st);
   return launch_tile<T, TileS, false>(d, a, v, st);
 }
 

@@ -60,6 +60,11 @@ struct GemmArgs {
   float* splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
   const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
+  // fp8 weights (precision "fp8w", bf16 activations): W is [N,K] OCP e4m3 BYTES (ldw / bsW in elements = bytes) and
+  // wscale[n] the per-output-channel dequantisation scale; the kernel widens the fragments to bf16 in registers and
+  // multiplies accumulator column n by wscale[n] before bias / activation. Needs N % 4 == 0, K % 64 == 0, batch 1.
+  int w8 = 0;
+  const float* wscale = nullptr;
 };
 // returns hipError_t as int; is_bf16 selects the operand type
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);

@@ -72,11 +72,33 @@ struct HostParam {
   std::vector<int64_t> shape;
 };
 
-struct Lin {            // packed nn.Linear-layout weight T [N,K] (+ optional fp32 bias [N])
-  void* W = nullptr;
+struct Lin {            // packed nn.Linear-layout weight [N,K] (+ optional fp32 bias [N]): operand type T, or -- precision
+  void* W = nullptr;    // "fp8w", large matrices -- OCP e4m3 bytes with one fp32 dequantisation scale per output channel
   float* b = nullptr;
   int N = 0, K = 0;
+  float* ws = nullptr;  // [N] scales; non-null <=> W holds fp8
 };
+
+// fp32 -> OCP FP8 E4M3 (e4m3fn: bias 7, no infinities, max 448), round to nearest even, saturating. Host side of the fp8w
+// weight format (the device side is v_cvt_pk_f32_fp8 in gemm.hip); exported as vima_fp8_e4m3_encode for the tests.
+uint8_t f32_to_e4m3(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint8_t sgn = (uint8_t)((u >> 24) & 0x80);
+  const float a = fabsf(f);
+  if (!(a == a)) return (uint8_t)(sgn | 0x7f);
+  if (a >= 464.0f) return (uint8_t)(sgn | 0x7e);                 // beyond the rounding range of 448: saturate
+  if (a < 0.015625f) return (uint8_t)(sgn | (uint8_t)(int)nearbyintf(a * 512.0f));   // subnormals: multiples of 2^-9 (8 -> 2^-6)
+  int e;
+  const float fr = frexpf(a, &e);                                // a = fr * 2^e, fr in [0.5, 1)
+  int E = e - 1;
+  int m = (int)nearbyintf((fr * 2.0f - 1.0f) * 8.0f);            // 3 mantissa bits, ties to even
+  if (m == 8) { m = 0; ++E; }
+  int code = ((E + 7) << 3) | m;
+  if (code > 0x7e) code = 0x7e;
+  return (uint8_t)(sgn | code);
+}
+inline bool fp8_eligible(int N, int K) { return K % 64 == 0 && N % 4 == 0 && (long long)N * K >= 65536; }
 
 struct Arena {          // stream-ordered bump allocator; chunks are only released at reset()
   struct Chunk { char* p; size_t cap; };
@@ -133,6 +155,7 @@ struct VimaHandle {
   VimaConfig cfg;
   int device = 0;
   bool bf16 = true;
+  bool w8 = false;          // precision "fp8w": bf16 activations / MFMA, fp8 e4m3 weights for the large Linear layers
   bool finalized = false;
   int attn_impl = 1;
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
@@ -254,6 +277,26 @@ struct Packer {
     if (hipMemcpy(d, t.data(), t.size() * 2, hipMemcpyHostToDevice) != hipSuccess) missing += "\n  hipMemcpy failed";
     return d;
   }
+  // weight of a Linear layer [l.N, l.K] row-major: operand type, or fp8 e4m3 + per-output-channel scale (amax / 448)
+  void pack_w(Lin& l, const std::vector<float>& w) {
+    if (!h->w8 || !fp8_eligible(l.N, l.K)) { l.W = up_T(w); return; }
+    std::vector<uint8_t> q((size_t)l.N * l.K);
+    std::vector<float> sc((size_t)l.N);
+    for (int n = 0; n < l.N; ++n) {
+      const float* row = &w[(size_t)n * l.K];
+      float amax = 0.f;
+      for (int k = 0; k < l.K; ++k) amax = fmaxf(amax, fabsf(row[k]));
+      const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+      sc[n] = scale;
+      for (int k = 0; k < l.K; ++k) q[(size_t)n * l.K + k] = f32_to_e4m3(row[k] / scale);
+    }
+    void* d = nullptr;
+    if (hipMalloc(&d, q.size() + 64) != hipSuccess) { missing += "\n  hipMalloc failed"; return; }
+    h->owned.push_back(d);
+    if (hipMemcpy(d, q.data(), q.size(), hipMemcpyHostToDevice) != hipSuccess) missing += "\n  hipMemcpy failed";
+    l.W = d;
+    l.ws = up_f32(sc.data(), sc.size());
+  }
   float* vec(const std::string& name, int64_t n) {
     const HostParam* p = get(name, {n});
     return p ? up_f32(p->data.data(), (size_t)n) : nullptr;
@@ -263,7 +306,7 @@ struct Packer {
     Lin l;
     l.N = N; l.K = K;
     const HostParam* w = get(prefix + wname, {N, K});
-    if (w) l.W = up_T(w->data);
+    if (w) pack_w(l, w->data);
     if (bias) l.b = vec(prefix + ".bias", N);
     return l;
   }
@@ -276,7 +319,7 @@ struct Packer {
       std::vector<float> t((size_t)N * K);
       for (int k = 0; k < K; ++k)
         for (int n = 0; n < N; ++n) t[(size_t)n * K + k] = w->data[(size_t)k * N + n];
-      l.W = up_T(t);
+      pack_w(l, t);
     }
     l.b = vec(prefix + ".bias", N);
     return l;
@@ -297,14 +340,14 @@ int pack_all(VimaHandle* h) {
   h->vit.lnpost_b = P.vec(v + "ln_post.bias", kVitW);
   if (const HostParam* p = P.get(v + "conv1.weight", {kVitW, 3, 16, 16})) {  // [768, 3*16*16] already [N,K]
     h->vit.conv.N = kVitW; h->vit.conv.K = 768;
-    h->vit.conv.W = P.up_T(p->data);
+    P.pack_w(h->vit.conv, p->data);
   }
   if (const HostParam* p = P.get(v + "projection", {kVitW, kVitW})) {        // x @ projection: [in,out] -> [out,in]
     std::vector<float> t((size_t)kVitW * kVitW);
     for (int k = 0; k < kVitW; ++k)
       for (int n = 0; n < kVitW; ++n) t[(size_t)n * kVitW + k] = p->data[(size_t)k * kVitW + n];
     h->vit.projection.N = kVitW; h->vit.projection.K = kVitW;
-    h->vit.projection.W = P.up_T(t);
+    P.pack_w(h->vit.projection, t);
   }
   for (int j = 0; j < kVitLayers; ++j) {
     snprintf(buf, sizeof buf, "%sblocks.%d.", v.c_str(), j);
@@ -313,7 +356,7 @@ int pack_all(VimaHandle* h) {
     B.ln1g = P.vec(b + "ln_1.weight", kVitW); B.ln1b = P.vec(b + "ln_1.bias", kVitW);
     B.ln2g = P.vec(b + "ln_2.weight", kVitW); B.ln2b = P.vec(b + "ln_2.bias", kVitW);
     B.in_proj.N = 3 * kVitW; B.in_proj.K = kVitW;
-    if (const HostParam* p = P.get(b + "attn.in_proj_weight", {3 * kVitW, kVitW})) B.in_proj.W = P.up_T(p->data);
+    if (const HostParam* p = P.get(b + "attn.in_proj_weight", {3 * kVitW, kVitW})) P.pack_w(B.in_proj, p->data);
     B.in_proj.b = P.vec(b + "attn.in_proj_bias", 3 * kVitW);
     B.out_proj = P.linear(b + "attn.out_proj", kVitW, kVitW, true);
     B.fc = P.linear(b + "mlp.c_fc", 4 * kVitW, kVitW, true);
@@ -344,7 +387,7 @@ int pack_all(VimaHandle* h) {
         }
       }
       h->fuse.N = E; h->fuse.K = E;
-      h->fuse.W = P.up_T(wm);
+      P.pack_w(h->fuse, wm);
       h->ee_table = P.up_f32(tab.data(), tab.size());
     }
   }
@@ -376,13 +419,13 @@ int pack_all(VimaHandle* h) {
       t.insert(t.end(), k->data.begin(), k->data.end());
       t.insert(t.end(), vv->data.begin(), vv->data.end());
       L.qkv.N = 3 * inner; L.qkv.K = kT5Model;
-      L.qkv.W = P.up_T(t);
+      P.pack_w(L.qkv, t);
       // (x_hat * g) W^T = x_hat (W diag(g))^T : the RMSNorm weight folded into the consumer (fused-RMSNorm path)
       if (const HostParam* g = P.get(a + "layer_norm.weight", {kT5Model})) {
         for (size_t n = 0; n < (size_t)3 * inner; ++n)
           for (int k = 0; k < kT5Model; ++k) t[n * kT5Model + k] *= g->data[k];
         L.qkv_g.N = 3 * inner; L.qkv_g.K = kT5Model;
-        L.qkv_g.W = P.up_T(t);
+        P.pack_w(L.qkv_g, t);
       }
     }
     L.o = P.linear(a + "SelfAttention.o", kT5Model, inner, false);
@@ -395,7 +438,7 @@ int pack_all(VimaHandle* h) {
         for (size_t n = 0; n < (size_t)kT5FF; ++n)
           for (int k = 0; k < kT5Model; ++k) t[n * kT5Model + k] *= g->data[k];
         L.wi_g.N = kT5FF; L.wi_g.K = kT5Model;
-        L.wi_g.W = P.up_T(t);
+        P.pack_w(L.wi_g, t);
       }
     }
     L.wo = P.linear(f + "DenseReluDense.wo", kT5Model, kT5FF, false);
@@ -461,7 +504,7 @@ int pack_all(VimaHandle* h) {
     }
     if (ok) {
       h->head1.N = kNumHeadsOut * kHeadHidden; h->head1.K = E;
-      h->head1.W = P.up_T(w1); h->head1.b = P.up_f32(b1.data(), b1.size());
+      P.pack_w(h->head1, w1); h->head1.b = P.up_f32(b1.data(), b1.size());
       h->head2_W = P.up_T(w2); h->head2_b = P.up_f32(b2.data(), b2.size());
     }
   }
@@ -543,11 +586,22 @@ struct Run {
                       " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + ")", e);
     return err;
   }
+  // weight operand of a GEMM from a packed Linear layer, optionally starting at output channel row0
+  void setW(GemmArgs& a, const Lin& L, int row0 = 0) const {
+    a.ldw = L.K;
+    if (L.ws) {
+      a.W = reinterpret_cast<const char*>(L.W) + (long long)row0 * L.K;
+      a.w8 = 1;
+      a.wscale = L.ws + row0;
+    } else {
+      a.W = offT(L.W, (long long)row0 * L.K);
+    }
+  }
   // out = act(A . W^T + b) [* mul] [+ res]
   int linear(const void* A, int lda, const Lin& L, int M, int act, const void* mul, int ldmul, const float* res, int ldres,
              float* out32, int ld32, void* outT, int ldT) {
     GemmArgs a;
-    a.A = A; a.lda = lda; a.W = L.W; a.ldw = L.K; a.M = M; a.N = L.N; a.K = L.K;
+    a.A = A; a.lda = lda; setW(a, L); a.M = M; a.N = L.N; a.K = L.K;
     a.bias = L.b; a.act = act; a.mul = mul; a.ldmul = ldmul; a.res = res; a.ldres = ldres;
     a.out32 = out32; a.ld32 = ld32; a.outT = outT; a.ldT = ldT;
     return gemm(a);
@@ -640,11 +694,11 @@ void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int 
     auto& B = h->vit.blk[kVitLayers - 1];
     R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
     GemmArgs kvg;   // K,V of all 5 tokens: in_proj rows [W, 3W)
-    kvg.A = b.hT; kvg.lda = kVitW; kvg.W = R.offT(B.in_proj.W, (long long)kVitW * kVitW); kvg.ldw = kVitW;
+    kvg.A = b.hT; kvg.lda = kVitW; R.setW(kvg, B.in_proj, kVitW);
     kvg.M = rows; kvg.N = 2 * kVitW; kvg.K = kVitW; kvg.bias = B.in_proj.b + kVitW; kvg.outT = b.qkv; kvg.ldT = 2 * kVitW;
     R.gemm(kvg);
     GemmArgs qg;    // Q of the cls token only: in_proj rows [0, W), A rows strided by 5 tokens
-    qg.A = b.hT; qg.lda = 5 * kVitW; qg.W = B.in_proj.W; qg.ldw = kVitW; qg.M = mc; qg.N = kVitW; qg.K = kVitW;
+    qg.A = b.hT; qg.lda = 5 * kVitW; R.setW(qg, B.in_proj, 0); qg.M = mc; qg.N = kVitW; qg.K = kVitW;
     qg.bias = B.in_proj.b; qg.outT = b.y; qg.ldT = kVitW;
     R.gemm(qg);
     R.prof_begin(1, 4.0 * mc * kVitHeads * 5.0 * 32);
@@ -712,7 +766,7 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
     void* catv = R.offT(cat, (long long)vi * per_view * 2 * kVitW);
     R.linear(t2, 768, h->view[vi].l2, per_view, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, R.offT(catv, kVitW), 2 * kVitW);
     GemmArgs a;
-    a.A = catv; a.lda = 2 * kVitW; a.W = h->view[vi].pre.W; a.ldw = 2 * kVitW; a.M = per_view; a.N = E; a.K = 2 * kVitW;
+    a.A = catv; a.lda = 2 * kVitW; R.setW(a, h->view[vi].pre); a.M = per_view; a.N = E; a.K = 2 * kVitW;
     a.bias = h->view[vi].pre.b;
     a.out32 = feat32; a.ld32 = E; a.outT = featT; a.ldT = E;
     a.rb = qv; a.s_hi = 2 * qv; a.s_lo = 1; a.ro = vi * qv;
@@ -789,7 +843,7 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
   auto gemm = [&](const void* A, int lda, const Lin& W, int act, const float* res, float* out32, void* outT, int ldT,
                   const float* rs, int rs_parts, float* ssq_out) {
     GemmArgs g;
-    g.A = A; g.lda = lda; g.W = W.W; g.ldw = W.K; g.M = rows; g.N = W.N; g.K = W.K; g.act = act;
+    g.A = A; g.lda = lda; R.setW(g, W); g.M = rows; g.N = W.N; g.K = W.K; g.act = act;
     g.res = res; g.ldres = kT5Model; g.out32 = out32; g.ld32 = kT5Model; g.outT = outT; g.ldT = ldT;
     g.rs_ssq = rs; g.rs_parts = rs_parts; g.rs_invk = 1.0f / (float)kT5Model; g.rs_eps = 1e-6f;
     g.ssq_out = ssq_out;
@@ -964,6 +1018,9 @@ extern "C" {
 int vima_abi_version(void) { return 1; }
 const char* vima_last_error(void) { return g_err.c_str(); }
 int vima_t5_bucket(int rel) { return t5_bucket(rel); }
+void vima_fp8_e4m3_encode(const float* src, uint8_t* dst, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_e4m3(src[i]);
+}
 
 int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   if (!cfg || !out) return fail("vima_create: null argument");
@@ -977,7 +1034,8 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   if (!head_ok(ds) || !head_ok(dx))
     return fail("vima_create: head dim must be 16, 32, 64 or 128 (got " + std::to_string(ds) + "/" + std::to_string(dx) + ")");
   if (E % 64 || E > 1024) return fail("vima_create: embed_dim must be a multiple of 64 and <= 1024");
-  if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16) return fail("vima_create: bad precision");
+  if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16 && cfg->precision != VIMA_PRECISION_FP8W)
+    return fail("vima_create: bad precision");
   if (cfg->n_positions <= 0 || cfg->n_positions > 512 || cfg->xattn_n_positions <= 0) return fail("vima_create: bad table sizes");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -987,7 +1045,8 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   VimaHandle* h = new VimaHandle();
   h->cfg = *cfg;
   h->device = device;
-  h->bf16 = cfg->precision == VIMA_PRECISION_BF16;
+  h->bf16 = cfg->precision != VIMA_PRECISION_FP32;
+  h->w8 = cfg->precision == VIMA_PRECISION_FP8W;
   if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -1051,7 +1110,7 @@ int64_t vima_required_params(const VimaConfig* cfg, char* buf, int64_t buflen) {
   // host-only: run the packer against an empty staging map and collect the "missing key" names
   if (!cfg) return -1;
   VimaHandle tmp;
-  tmp.cfg = *cfg; tmp.bf16 = cfg->precision == VIMA_PRECISION_BF16;
+  tmp.cfg = *cfg; tmp.bf16 = cfg->precision != VIMA_PRECISION_FP32;
   std::string saved = g_err;
   (void)pack_all(&tmp);
   std::string msg = g_err;
@@ -1377,11 +1436,11 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
       // (row b*Lq + i -> b*Lmax + L_hist + i); the new queries attend to history + themselves with a causal offset
       void* cache = reinterpret_cast<char*>(h->ep_kv) + (size_t)i * B * Lmax * 2 * E * h->esz();
       GemmArgs gq;
-      gq.A = xT; gq.lda = E; gq.W = D.c_attn.W; gq.ldw = E; gq.M = rq; gq.N = E; gq.K = E; gq.bias = D.c_attn.b;
+      gq.A = xT; gq.lda = E; R.setW(gq, D.c_attn, 0); gq.M = rq; gq.N = E; gq.K = E; gq.bias = D.c_attn.b;
       gq.outT = qkv; gq.ldT = E;
       R.gemm(gq);
       GemmArgs gk;
-      gk.A = xT; gk.lda = E; gk.W = R.offT(D.c_attn.W, (long long)E * E); gk.ldw = E; gk.M = rq; gk.N = 2 * E; gk.K = E;
+      gk.A = xT; gk.lda = E; R.setW(gk, D.c_attn, E); gk.M = rq; gk.N = 2 * E; gk.K = E;
       gk.bias = D.c_attn.b ? D.c_attn.b + E : nullptr;
       gk.outT = cache; gk.ldT = 2 * E; gk.rb = Lq; gk.s_hi = Lmax; gk.s_lo = 1; gk.ro = L_hist;
       R.gemm(gk);
@@ -1461,7 +1520,7 @@ int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logi
   int col = 0;
   for (int j = 0; j < kNumHeadsOut; ++j) {
     GemmArgs b;
-    b.A = R.offT(h2, (long long)j * kHeadHidden); b.lda = HH; b.W = h->head3[j].W; b.ldw = kHeadHidden;
+    b.A = R.offT(h2, (long long)j * kHeadHidden); b.lda = HH; R.setW(b, h->head3[j]);
     b.M = Rn; b.N = kHeadBins[j]; b.K = kHeadHidden; b.bias = h->head3[j].b;
     b.out32 = out_logits + col; b.ld32 = kLogits;
     R.gemm(b);
