@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--qv", type=int, default=4, help="objects per view (Q = 2*qv object tokens per observation)")
     ap.add_argument("--words", type=int, default=8, help="words per prompt segment (a segment = words + 1 image)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8w"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--steps-history", type=int, default=1, help="T: observation steps in the history (T-1 past actions)")
@@ -269,7 +269,7 @@ def main():
     # the same model / prompt, each with the roofline that binds it (batch 1: the ~676 MB of bf16 weights over HBM;
     # batch 32: bf16 MFMA)
     secondary = {}
-    WEIGHT_BYTES = 676e6 if args.precision == "bf16" else 1352e6          # weights touched once per pass
+    WEIGHT_BYTES = {"bf16": 676e6, "fp8w": 370e6, "fp32": 1352e6}[args.precision]          # weights touched once per pass
     for b2 in (1, 32):
         if b2 >= B:
             continue
@@ -291,7 +291,7 @@ def main():
         sync()
         ms2 = (time.perf_counter() - t0) / n2 * 1e3
         cold2, _ = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, 1)
-        t_mfma = b2 * cold2 / ((BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS) * 1e12) * 1e3
+        t_mfma = b2 * cold2 / ((FP32_PEAK_TFLOPS if args.precision == "fp32" else BF16_PEAK_TFLOPS) * 1e12) * 1e3
         t_hbm = WEIGHT_BYTES / 8e12 * 1e3
         secondary[f"batch_{b2}"] = {
             "ms_per_step": round(ms2, 3), "steps_per_s": round(1e3 / ms2, 2), "samples_per_s": round(b2 * 1e3 / ms2, 1),
@@ -312,11 +312,11 @@ def main():
     pol.prof_enable(False)
 
     cold, warm = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, T)
-    peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
+    peak = FP32_PEAK_TFLOPS if args.precision == "fp32" else BF16_PEAK_TFLOPS   # fp8w: fp8 weights are widened to bf16 in registers, the matrix op is the bf16 MFMA
     gemm = prof["gemm"]
     gemm_tflops = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
     roofline = {
-        "bound": "mfma", "kernel": "vima::gemm_persistent_kernel / vima::gemm_kernel (bf16 mfma_f32_32x32x16; all GEMM launches of a step)" if args.precision == "bf16" else "vima::gemm_kernel (fp32 mfma)",
+        "bound": "mfma", "kernel": "vima::gemm_persistent_kernel / vima::gemm_kernel (bf16 mfma_f32_32x32x16; all GEMM launches of a step)" if args.precision != "fp32" else "vima::gemm_kernel (fp32 mfma)",
         "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
         "traffic": pmc_traffic(),
         "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / max(gemm["launches"], 1), 2),

@@ -635,14 +635,15 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
   int iv, ikt = 0;
   const int r0 = (w * 64 + lane) / CPR;                 // row of this lane within a 64-row piece group
   const int c0 = ((lane % CPR) ^ swz<RB>(r0)) * 16;     // swizzled 16-B chunk (the same for every piece: swz ignores r / 64)
-  const int r0w = (w * 64 + lane) / CPRW;               // the same for the W tile (128-row piece groups when its rows are 64 B)
-  const int c0w = ((lane % CPRW) ^ swz<RBW>(r0w)) * 16;
+
   auto set_ptrs = [&](int v) {
     int tm, tn;
     tile_at(v, tm, tn);
 #pragma unroll
     for (int i = 0; i < TL::PA; ++i)
       offA[i] = (unsigned)(tm * TL::BM + i * (NW * 64 / CPR) + r0) * (unsigned)(p.lda * (int)sizeof(T)) + c0;
+    const int r0w = W8 ? (w * 64 + lane) / CPRW : r0;     // W tile rows of 64 B (fp8): 128-row piece groups; recomputed
+    const int c0w = W8 ? ((lane % CPRW) ^ swz<RBW>(r0w)) * 16 : c0;   // per tile so that nothing extra stays live in the main loop
 #pragma unroll
     for (int i = 0; i < PWN; ++i)
       offW[i] = (unsigned)(tn * TL::BN + i * (NW * 64 / CPRW) + r0w) * (unsigned)(p.ldw * ESW) + c0w;
@@ -702,11 +703,13 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     // fused RMSNorm: scales of this lane's four accumulator rows, fetched at the START of the tile (the wave is about to
     // wait for its first K-slice anyway; in the epilogue the same loads would queue behind the next tile's LDS-DMA)
     float rscv[MI];
+    int tl31 = l31;                     // opaque per tile: the row indices below are tile-invariant up to m0 and would
+    asm volatile("" : "+v"(tl31));      // otherwise be hoisted out of the tile loop and held (spilled) across the main loop
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       rscv[mi] = 1.0f;
       if ((EPI == 0 || EPI == 1) && p.rs_ssq) {
-        int mr = m0 + wm * (MI * 32) + mi * 32 + l31; mr = mr < p.M ? mr : p.M - 1;
+        int mr = m0 + wm * (MI * 32) + mi * 32 + tl31; mr = mr < p.M ? mr : p.M - 1;
         rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
       }
     }
@@ -820,7 +823,12 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
         for (int q = 0; q < 4; ++q) {
           float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
           const int nb = nbase + 8 * q + 4 * ehi;
-          if (W8) { const float4 sc = load4(p.wscale + nb); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }   // per-output-channel dequantisation
+          if (W8) {   // per-output-channel dequantisation. The index is made opaque per slab: the scales do not depend on mi and
+            int nbs = nb;   // hipcc would otherwise keep all 32 of them live across the tile (spills)
+            asm volatile("" : "+v"(nbs));
+            const float4 sc = load4(p.wscale + nbs);
+            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+          }
           if (p.bias && nb < p.N) { const float4 b = load4(p.bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
           if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
           *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
