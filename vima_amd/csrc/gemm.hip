@@ -798,106 +798,135 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
     auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
     float* stg = reinterpret_cast<float*>(smem + EPI_OFF + w * 4096);
-    const bool wide8 = EPI == 0 ? p.wide8 != 0 : (EPI == 1 || EPI == 2);
-    const T* mul = (EPI == 0 || EPI == 2) ? reinterpret_cast<const T*>(p.mul) : nullptr;
-    const float* res = (EPI == 0 || EPI == 3) ? p.res : nullptr;
-    float* out32 = (EPI == 0 || EPI == 3) ? p.out32 : nullptr;
+    constexpr bool WIDE8 = EPI == 1 || EPI == 2;                  // bf16-only output, 16-byte stores
+    const T* mul = EPI == 2 ? reinterpret_cast<const T*>(p.mul) : nullptr;
+    const float* res = EPI == 3 ? p.res : nullptr;
+    float* out32 = EPI == 3 ? p.out32 : nullptr;
     T* outT = reinterpret_cast<T*>(p.outT);
-    const float* rs_ssq = (EPI == 0 || EPI == 1) ? p.rs_ssq : nullptr;
-    float* ssq_out = (EPI == 0 || EPI == 3) ? p.ssq_out : nullptr;
-    const int rb = EPI == 0 ? p.rb : 0;
+    float* ssq_out = EPI == 3 ? p.ssq_out : nullptr;
     // the epilogue's per-lane address arithmetic is tile-invariant: hipcc would hoist it out of the tile loop and keep
     // (spill) it across the main loop. An opaque copy of the lane id pins it here.
     int elane = lane;
     asm volatile("" : "+v"(elane));
     const int el31 = elane & 31, ehi = elane >> 5;
     const int fw_ = fsw(el31);
+    // Two phases per 32x32 slab: (1) the accumulators (x fused-RMSNorm row scale) go to the wave's LDS slab in MFMA
+    // layout; (2) they are read back ROW-CONTIGUOUSLY -- a lane owns 8 (bf16-only output) or 4 consecutive columns of a
+    // row, the SAME columns for every row and every mi -- and finished there: x weight scale (fp8w), + bias, activation,
+    // x gate, + residual, stores. Everything that depends on the column only (bias, fp8 scales) is therefore loaded once
+    // per tile. The per-row operands (gate / residual) are prefetched ONE SLAB AHEAD with inline-asm loads and counted
+    // `vmcnt` waits: left to hipcc, every row group waited `vmcnt(0)`, i.e. for the previous group's STORES as well (32
+    // serialised store round trips per tile, ~25 us of a 50 us tile at K = 768). VMEM operations of a wave retire in issue
+    // order; the launcher only sends M % 256 == 0, N % 256 == 0 here, so there are no bounds checks.
+    constexpr int CPL = WIDE8 ? 8 : 4;                            // columns per lane in the read-back layout
+    constexpr int LPR = 32 / CPL;                                 // lanes per slab row
+    constexpr int RPI = 64 / LPR;                                 // rows per wave-instruction (16 / 8)
+    constexpr int NIT = 32 / RPI;                                 // row groups per slab (2 / 4)
+    const int ccol = (elane % LPR) * CPL;                         // first column of this lane inside a slab
+    const int crow = elane / LPR;                                 // row of this lane inside a row group
+    const int ncol0 = n0 + wn * (NI * 32) + ccol;                 // + ni * 32
+    const int mrow0 = m0 + wm * (MI * 32) + crow;                 // + mi * 32 + it * RPI
+    float4 bcol[NI][CPL / 4], scol[NI][CPL / 4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < CPL / 4; ++j) {
+        bcol[ni][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        scol[ni][j] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.bias) bcol[ni][j] = load4(p.bias + ncol0 + ni * 32 + 4 * j);
+        if (W8) scol[ni][j] = load4(p.wscale + ncol0 + ni * 32 + 4 * j);
+      }
+    // the column constants are needed (waited for) HERE, before the per-row prefetch starts: hipcc would otherwise wait for
+    // them at their first use with `vmcnt(0)`, i.e. for the prefetched loads issued in between as well
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < CPL / 4; ++j) {
+        if (p.bias) asm volatile("" : "+v"(bcol[ni][j].x), "+v"(bcol[ni][j].y), "+v"(bcol[ni][j].z), "+v"(bcol[ni][j].w));
+        if (W8) asm volatile("" : "+v"(scol[ni][j].x), "+v"(scol[ni][j].y), "+v"(scol[ni][j].z), "+v"(scol[ni][j].w));
+      }
+    // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
+    constexpr bool AUX = EPI == 2 || EPI == 3;
+    const char* auxp = nullptr;
+    long long aux_ld = 0;                                         // bytes per row
+    if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
+    if (EPI == 3) { auxp = reinterpret_cast<const char*>(res + (long long)mrow0 * p.ldres + ncol0); aux_ld = (long long)p.ldres * 4; }
+    f32x4_t aux[2][NIT];
+    auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {
+      const int mi = sl / NI, ni = sl % NI;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 2 ? 2 : 4);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
+      }
+    };
+    if (AUX) issue_aux(0, aux[0]);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const float rsc = rscv[mi];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int nbase = n0 + wn * (NI * 32) + ni * 32;
-        const int mbase = m0 + wm * (MI * 32) + mi * 32;
+        constexpr int NSLAB = MI * NI;
+        const int sl = mi * NI + ni;
+        // ---- (1) stage
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
-          const int nb = nbase + 8 * q + 4 * ehi;
-          if (W8) {   // per-output-channel dequantisation. The index is made opaque per slab: the scales do not depend on mi and
-            int nbs = nb;   // hipcc would otherwise keep all 32 of them live across the tile (spills)
-            asm volatile("" : "+v"(nbs));
-            const float4 sc = load4(p.wscale + nbs);
-            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-          }
-          if (p.bias && nb < p.N) { const float4 b = load4(p.bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-          if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+          const float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
           *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
         }
-        // read-back, software-pipelined by one row group: the gate / residual loads of group it+1 are issued BEFORE the
-        // stores of group it (a load issued behind stores waits for them to drain: vmcnt retires in order)
-        if (wide8) {   // bf16-only output: 4 lanes x 16 B per row, 16 rows per instruction
-          const int c8 = elane & 3;
-          const int n8 = nbase + c8 * 8;
-          float4 g0n, g1n, r0n, r1n;
-          auto load_aux = [&](int it) {
-            const int m = mbase + it * 16 + (elane >> 2);
-            if (m < p.M && n8 < p.N) {
-              if (mul) { g0n = load4(mul + (long long)m * p.ldmul + n8); g1n = load4(mul + (long long)m * p.ldmul + n8 + 4); }
-              if (res) { r0n = load4(res + (long long)m * p.ldres + n8); r1n = load4(res + (long long)m * p.ldres + n8 + 4); }
-            }
-          };
-          load_aux(0);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int r = it * 16 + (elane >> 2);
-            const int f = fsw(r);
-            float4 v0 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8) ^ f) << 2));
-            float4 v1 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8 + 1) ^ f) << 2));
-            const float4 g0 = g0n, g1 = g1n, r0 = r0n, r1 = r1n;
-            if (it + 1 < 2) load_aux(it + 1);
-            const int m = mbase + r;
-            if (m < p.M && n8 < p.N) {
-              long long orow = m;
-              if (rb > 0) orow = (long long)(m / rb) * p.s_hi + (long long)(m % rb) * p.s_lo + p.ro;
-              if (mul) { v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w; v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w; }
-              if (res) { v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w; }
-              uint4 o;
-              o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
-              *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
-            }
+        // ---- prefetch the next slab's per-row operand, then wait for this slab's (issued one slab ago). Younger VMEM
+        // operations at that point: the stores of the previous slab (EPI 2: exactly NIT; EPI 3: at least NIT) and the NIT
+        // loads just issued -- a smaller count only waits for a few more (older) stores.
+        if (AUX) {
+          if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
+          constexpr int kYoungLoads = NIT;
+          f32x4_t(&a)[NIT] = aux[sl & 1];
+          if (sl == 0 || sl + 1 == NSLAB) {
+            if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(kYoungLoads));
+            else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(kYoungLoads));
+          } else {
+            if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(2 * kYoungLoads));
+            else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(2 * kYoungLoads));
           }
-        } else {         // 8 lanes x 16 B (fp32) per row, 8 rows per instruction
-          const int cc = elane & 7;
-          const int n = nbase + cc * 4;
-          float4 gn, rn;
-          auto load_aux = [&](int it) {
-            const int m = mbase + it * 8 + (elane >> 3);
-            if (m < p.M && n < p.N) {
-              if (mul) gn = load4(mul + (long long)m * p.ldmul + n);
-              if (res) rn = load4(res + (long long)m * p.ldres + n);
-            }
-          };
-          load_aux(0);
+        }
+        // ---- (2) read back and finish
+        const int n = ncol0 + ni * 32;
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + (elane >> 3);
-            float4 v = *reinterpret_cast<const float4*>(stg + r * 32 + ((cc ^ fsw(r)) << 2));
-            const float4 g = gn, r4 = rn;
-            if (it + 1 < 4) load_aux(it + 1);
-            const int m = mbase + r;
-            float sq = 0.f;
-            if (m < p.M && n < p.N) {
-              long long orow = m;
-              if (rb > 0) orow = (long long)(m / rb) * p.s_hi + (long long)(m % rb) * p.s_lo + p.ro;
-              if (mul) { v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
-              if (res) { v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
-              if (out32) store4(out32 + orow * p.ld32 + n, v);
-              if (outT) store4(outT + orow * p.ldT + n, v);
-              sq = sumsq4(v);
-            }
+        for (int it = 0; it < NIT; ++it) {
+          const int r = it * RPI + crow;
+          const int f = fsw(r);
+          const long long m = mrow0 + mi * 32 + it * RPI;
+          float4 v[CPL / 4];
+#pragma unroll
+          for (int j = 0; j < CPL / 4; ++j) {
+            v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
+            if (W8) { v[j].x *= scol[ni][j].x; v[j].y *= scol[ni][j].y; v[j].z *= scol[ni][j].z; v[j].w *= scol[ni][j].w; }
+            if (p.bias) { v[j].x += bcol[ni][j].x; v[j].y += bcol[ni][j].y; v[j].z += bcol[ni][j].z; v[j].w += bcol[ni][j].w; }
+            if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
+          }
+          if constexpr (EPI == 2) {        // x gate: 8 bf16 values
+            const f32x4_t g = aux[sl & 1][it];
+            const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
+            v[0].x *= __uint_as_float(g0 << 16); v[0].y *= __uint_as_float(g0 & 0xffff0000u);
+            v[0].z *= __uint_as_float(g1 << 16); v[0].w *= __uint_as_float(g1 & 0xffff0000u);
+            v[1].x *= __uint_as_float(g2 << 16); v[1].y *= __uint_as_float(g2 & 0xffff0000u);
+            v[1].z *= __uint_as_float(g3 << 16); v[1].w *= __uint_as_float(g3 & 0xffff0000u);
+          }
+          if constexpr (EPI == 3) {        // + residual: 4 fp32 values
+            const f32x4_t r4 = aux[sl & 1][it];
+            v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
+          }
+          if constexpr (WIDE8) {
+            uint4 o;
+            o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
+            *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+          } else {
+            store4(out32 + m * p.ld32 + n, v[0]);
+            if (outT) store4(outT + m * p.ldT + n, v[0]);
             if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly, one partial per row and slab
+              float sq = sumsq4(v[0]);
               sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-              if ((elane & 7) == 0 && m < p.M && n < p.N) ssq_out[(long long)m * (p.N >> 5) + (nbase >> 5)] = sq;   // plain store: deterministic
+              if ((elane & 7) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;   // plain store: deterministic
             }
           }
         }
@@ -1015,7 +1044,9 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
   d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
-  const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
+  int cus = g_num_cu;
+  if (a.tune && a.tune->gemm_persist_cus >= 8 && a.tune->gemm_persist_cus < cus) cus = a.tune->gemm_persist_cus / 8 * 8;
+  const int grid = d.vtotal < cus ? d.vtotal : cus;
   // specialised epilogues for the combinations the policy uses; everything else takes the generic instantiation
   int epi = 0;
   if (a.rb == 0) {
