@@ -25,20 +25,22 @@ def main():
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * 0.03
     out = torch.empty(M, N, device="cuda")
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    res = torch.randn(M, N, device="cuda") if os.environ.get("RES") else None       # residual epilogue (fp32 in / fp32 out)
+    bias = torch.randn(N, device="cuda") if os.environ.get("BIAS") else None
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     for _ in range(iters):
-        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, 0, p(out), pol._stream()))
+        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), p(bias), None, p(res), M, N, K, int(os.environ.get('ACT', '0')), p(out), pol._stream()))
     torch.cuda.synchronize()
     pol.prof_enable(True)
     for _ in range(iters):
-        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, 0, p(out), pol._stream()))
+        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), p(bias), None, p(res), M, N, K, int(os.environ.get('ACT', '0')), p(out), pol._stream()))
     torch.cuda.synchronize()
     pr = pol.prof_read()["gemm"]
     if os.environ.get("STAMPS"):
         nblk = ((M + 255) // 256 + 7) // 8 * 8 * ((N + 255) // 256) if tile in (2, 4, 5, 6) or (tile == 0 and M >= 8192) else ((M + 127) // 128 + 7) // 8 * 8 * ((N + 127) // 128)
         dbg = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
         pol.set_option("gemm_dbg_ptr", dbg.data_ptr())
-        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, 0, p(out), pol._stream()))
+        _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), p(bias), None, p(res), M, N, K, int(os.environ.get('ACT', '0')), p(out), pol._stream()))
         torch.cuda.synchronize()
         pol.set_option("gemm_dbg_ptr", 0)
         raw = dbg.view(-1, 8).cpu()

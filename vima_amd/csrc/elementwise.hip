@@ -540,16 +540,4 @@ int launch_gather_pred(const float* x, float* out, int T, int B, int Q, int Lq, 
   return (int)hipGetLastError();
 }
 
-namespace {
-__global__ __launch_bounds__(64) void delay_kernel(long long ticks) {   // s_memrealtime counts at 100 MHz
-  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-}  // namespace
-int launch_delay(int us, hipStream_t st) {
-  if (us <= 0) return 0;
-  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, (long long)us * 100);
-  return (int)hipGetLastError();
-}
-
 }  // namespace vima

@@ -1044,9 +1044,7 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
   d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
-  int cus = g_num_cu;
-  if (a.tune && a.tune->gemm_persist_cus >= 8 && a.tune->gemm_persist_cus < cus) cus = a.tune->gemm_persist_cus / 8 * 8;
-  const int grid = d.vtotal < cus ? d.vtotal : cus;
+  const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
   // specialised epilogues for the combinations the policy uses; everything else takes the generic instantiation
   int epi = 0;
   if (a.rb == 0) {

@@ -15,8 +15,6 @@ struct Tuning {
   int gemm_persist = -1;   // VIMA_GEMM_PERSIST  1 = large bf16 GEMMs on the persistent kernel (default)
   int gemm_small = -1;     // VIMA_GEMM_SMALL    1 = 64x64 / 32x64 tiles for underfilled grids (default)
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
-  int gemm_persist_cus = -1;   // workgroups (= CUs) of a persistent GEMM launch; default: every CU. With two streams each
-                               // taking half the chip, the HBM-heavy epilogues of one overlap the main loops of the other
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
   int attn4_min_lq = -1;   // Lq from which the 4-wave LDS-shared flash kernel is used (default 64)
@@ -82,8 +80,6 @@ int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
 int launch_cast(const float* in, void* outT, long long n, bool is_bf16, hipStream_t st);
-// one idle wave that spins for `us` microseconds (s_memrealtime): skews the auxiliary stream against the main one
-int launch_delay(int us, hipStream_t st);
 // operand-type copy of fp32 rows + their sum of squares (entry point of the fused-RMSNorm chain): outT[r][:] = in[r][:],
 // ssq[r] = sum in[r][:]^2
 int launch_rms_stats(const float* in, int rows, int E, void* outT, float* ssq, bool is_bf16, hipStream_t st);

@@ -165,7 +165,6 @@ struct VimaHandle {
   int op_bf16_out = 0;      // vima_op_linear: route the result through the operand-type output (tests the T store paths)
   int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
                             // GEMM epilogues) of one half overlap the MFMA-bound GEMM main loops of the other half
-  int dual_skew_us = 0;     // experiment: the auxiliary stream starts this many microseconds after the fork
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<hipEvent_t> ev_layer;   // per decoder layer: "prompt K/V of layer i projected" (aux -> main)
@@ -647,7 +646,6 @@ struct Run {
 int fork_aux(Run& R) {
   HIPCK(hipEventRecord(R.h->ev_fork, R.st));
   HIPCK(hipStreamWaitEvent(R.h->aux, R.h->ev_fork, 0));
-  if (R.h->dual_skew_us > 0) KCK(launch_delay(R.h->dual_skew_us, R.h->aux));
   return 0;
 }
 int join_aux(Run& R) {
@@ -1151,8 +1149,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_persist") h->tune.gemm_persist = (int)value;
   else if (k == "gemm_splitk") h->tune.gemm_splitk = (int)value;
   else if (k == "gemm_small") h->tune.gemm_small = (int)value;
-  else if (k == "gemm_persist_cus") h->tune.gemm_persist_cus = (int)value;
-  else if (k == "dual_skew_us") h->dual_skew_us = (int)value;
+
   else if (k == "gemm_dbg_ptr") h->tune.gemm_dbg = reinterpret_cast<long long*>((uintptr_t)value);
   else if (k == "attn4_min_lq") h->tune.attn4_min_lq = (int)value;
   else if (k == "attn_dbg_ptr") h->tune.attn_dbg = reinterpret_cast<long long*>((uintptr_t)value);
