@@ -184,6 +184,10 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value);
  * {milliseconds, launches, algorithmic FLOPs (2*M*N*K for GEMMs, 4*B*H*Lq*Lk*D for attention)}; then resets. */
 int vima_prof_enable(VimaHandle* h, int on);
 int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], double out_flops[3]);
+/* The same with the GEMM class split in two and the ALGORITHMIC HBM bytes of every GEMM launch (each operand, output and
+ * epilogue input counted once): class 0 = GEMMs without, class 3 = GEMMs with an fp32-residual epilogue (read fp32
+ * residual, write the fp32 stream [+ operand-type copy + RMS partials]: the HBM-heavy ones), 1 = attention, 2 = other. */
+int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]);
 /* bytes currently held by the workspace arena */
 int64_t vima_workspace_bytes(VimaHandle* h);
 /* hipGraph replay (vima_set_option(h, "graphs", 1)): the per-env-step entry points (vima_obs_encode, vima_decode,

@@ -2,12 +2,12 @@
 # Profiler databases are summarised on the box (gpurun only merges <= 64 MiB back).
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-TAG=${1:-r01_v4}
+TAG=${1:-r02_v1}
 cd $R
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest_all.txt 2>&1; tail -3 $O/pytest_all.txt
+timeout 1200 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" > $O/${TAG}_pytest.txt; tail -3 $O/${TAG}_pytest.txt; grep -E "\[parity\]|\[fp8w\]" $O/${TAG}_pytest.txt
 timeout 600 python bench.py --steps 8 --warmup 3 > $O/${TAG}_bench.json 2> $O/bench_stderr.txt; cat $O/${TAG}_bench.json | cut -c1-2500
 cd /tmp && export TMPDIR=/tmp
-TITLE="Round 1 ($TAG): rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --opt dual_stream=0, VIMA-200M B=256 Lp=512 bf16, 1x MI355X"
+TITLE="Round 2 ($TAG): rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --opt dual_stream=0, VIMA-200M B=256 Lp=512 bf16, 1x MI355X"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_final -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --opt dual_stream=0 > $O/prof_stdout.txt 2>&1
 python $R/scripts/rocprof_summary.py /tmp/prof_final/bench_results.db $O/${TAG}_kernel_stats.md "$TITLE"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --opt dual_stream=0 > /dev/null 2>&1

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "vima_prof_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "vima_prof_read": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
                                       ctypes.POINTER(ctypes.c_double)]),
+    "vima_prof_read_ex": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "vima_workspace_bytes": (c_i64, [vp]),
     "vima_graph_stats": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "vima_crop_objects": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,

@@ -147,7 +147,7 @@ struct Arena {          // stream-ordered bump allocator; chunks are only releas
   }
 };
 
-struct ProfRec { int cls; hipEvent_t a, b; double flops; };
+struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; };
 
 }  // namespace
 
@@ -540,7 +540,7 @@ struct Run {
   VimaHandle* h;
   hipStream_t st;
   int err = 0;
-  void prof_begin(int cls, double flops) {
+  void prof_begin(int cls, double flops, double bytes = 0.0) {
     if (!h->prof) return;
     if (h->ev_used + 2 > h->ev_pool.size()) {
       for (int i = 0; i < 256; ++i) {
@@ -549,7 +549,7 @@ struct Run {
         h->ev_pool.push_back(e);
       }
     }
-    ProfRec r{cls, h->ev_pool[h->ev_used], h->ev_pool[h->ev_used + 1], flops};
+    ProfRec r{cls, h->ev_pool[h->ev_used], h->ev_pool[h->ev_used + 1], flops, bytes};
     h->ev_used += 2;
     (void)hipEventRecord(r.a, st);
     h->recs.push_back(r);
@@ -579,7 +579,13 @@ struct Run {
       a.splitk_ws_bytes = wsb;
       if (err) return err;
     }
-    prof_begin(0, 2.0 * a.M * (double)a.N * a.K * (a.batch > 0 ? a.batch : 1));
+    {   // class 3 = GEMMs whose epilogue adds an fp32 residual and writes the fp32 stream (the HBM-heavy ones); algorithmic
+        // bytes = each operand / output / epilogue input once
+      const double nb = a.batch > 0 ? a.batch : 1, es = (double)h->esz(), mn = (double)a.M * a.N;
+      const double bytes = nb * ((double)a.M * a.K * es + (double)a.N * a.K * (a.w8 ? 1.0 : es) + (a.out32 ? mn * 4 : 0) + (a.outT ? mn * es : 0) +
+                                 (a.res ? mn * 4 : 0) + (a.mul ? mn * es : 0) + (a.ssq_out ? (double)a.M * (a.N / 32) * 4 : 0));
+      prof_begin((a.res && a.out32) ? 3 : 0, 2.0 * a.M * (double)a.N * a.K * nb, bytes);
+    }
     int e = launch_gemm(a, h->bf16, st);
     prof_end();
     if (e) err = fail(std::string("gemm launch failed: ") + hipGetErrorString((hipError_t)e) + " (M=" + std::to_string(a.M) +
@@ -1171,9 +1177,9 @@ int vima_prof_enable(VimaHandle* h, int on) {
   return 0;
 }
 
-int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], double out_flops[3]) {
+int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]) {
   if (!h) return fail("null handle");
-  for (int i = 0; i < 3; ++i) { out_ms[i] = 0; out_launches[i] = 0; out_flops[i] = 0; }
+  for (int i = 0; i < 4; ++i) { out_ms[i] = 0; out_launches[i] = 0; out_flops[i] = 0; out_bytes[i] = 0; }
   for (auto& r : h->recs) {
     HIPCK(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -1181,9 +1187,19 @@ int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], dou
     out_ms[r.cls] += ms;
     out_launches[r.cls] += 1;
     out_flops[r.cls] += r.flops;
+    out_bytes[r.cls] += r.bytes;
   }
   h->recs.clear();
   h->ev_used = 0;
+  return 0;
+}
+
+int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], double out_flops[3]) {
+  double ms[4], fl[4], by[4];
+  int64_t n[4];
+  if (int e = vima_prof_read_ex(h, ms, n, fl, by)) return e;
+  ms[0] += ms[3]; n[0] += n[3]; fl[0] += fl[3];   // class 3 is a GEMM class
+  for (int i = 0; i < 3; ++i) { out_ms[i] = ms[i]; out_launches[i] = n[i]; out_flops[i] = fl[i]; }
   return 0;
 }
 

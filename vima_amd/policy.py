@@ -500,5 +500,16 @@ class VIMAPolicy(nn.Module):
         names = ("gemm", "attention", "other")
         return {names[i]: {"ms": ms[i], "launches": int(n[i]), "flops": fl[i]} for i in range(3)}
 
+    def prof_read_ex(self):
+        """Like prof_read with the GEMMs split into "gemm" (no residual epilogue) and "gemm_residual" (fp32-residual
+        epilogue) and the algorithmic HBM bytes of the GEMM launches."""
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_int64 * 4)()
+        fl = (ctypes.c_double * 4)()
+        by = (ctypes.c_double * 4)()
+        _lib.check(self._lib.vima_prof_read_ex(self._handle, ms, n, fl, by))
+        names = ("gemm", "attention", "other", "gemm_residual")
+        return {names[i]: {"ms": ms[i], "launches": int(n[i]), "flops": fl[i], "bytes": by[i]} for i in range(4)}
+
     def workspace_bytes(self) -> int:
         return int(self._lib.vima_workspace_bytes(self._handle)) if self._handle is not None else 0
