@@ -12,14 +12,14 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 4;  // float4 per lane -> E <= 1024
 
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, long long ldin,
+template <typename T, typename TIN = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ in, long long ldin,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, int rms, int rows, int E, float* out32, T* outT) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* x = in + (long long)row * ldin;
+  const TIN* x = in + (long long)row * ldin;
   const int nv = E >> 2;  // float4 count (E % 4 == 0)
   float4 v[LN_MAXV];
   float s = 0.f;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      v[i] = *reinterpret_cast<const float4*>(x + c * 4);
+      v[i] = load4(x + c * 4);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     } else {
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -416,6 +416,16 @@ int launch_layernorm(const float* in, long long ldin, const float* gamma, const 
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, rms,
                        rows, E, out32, (float*)outT);
+  return (int)hipGetLastError();
+}
+
+int launch_layernorm_T(const void* inT, long long ldin, const float* gamma, const float* beta, float eps, int rms, int rows,
+                       int E, float* out32, void* outT, bool is_bf16, hipStream_t st) {
+  if (!is_bf16) return launch_layernorm((const float*)inT, ldin, gamma, beta, eps, rms, rows, E, out32, outT, false, st);
+  if (rows <= 0) return 0;
+  if (E % 4 != 0 || E > 64 * 4 * LN_MAXV || ldin % 4 != 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const bf16_t*)inT, ldin, gamma, beta,
+                     eps, rms, rows, E, out32, (bf16_t*)outT);
   return (int)hipGetLastError();
 }
 

@@ -185,6 +185,16 @@ __device__ __forceinline__ float sumsq4(const float4& v) {
   return __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
 }
 
+// sum of squares of 8 consecutive STORED bf16 values (the residual stream carried in bf16: its RMS statistics are those of
+// the rounded values the consumer multiplies with); fixed order, shared by every kernel that produces such partials
+__device__ __forceinline__ float sumsq8_bf16(const uint4& o) {
+  const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
+  const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
+  const float a4 = __uint_as_float(o.z << 16), a5 = __uint_as_float(o.z & 0xffff0000u);
+  const float a6 = __uint_as_float(o.w << 16), a7 = __uint_as_float(o.w & 0xffff0000u);
+  return sumsq4(make_float4(a0, a1, a2, a3)) + sumsq4(make_float4(a4, a5, a6, a7));
+}
+
 struct GemmDev {
   const void* A; const void* W;
   int M, N, K, lda, ldw;
@@ -192,6 +202,7 @@ struct GemmDev {
   const float* bias; int act;
   const void* mul; int ldmul;
   const float* res; int ldres;
+  const void* resT; int ldresT;
   float* out32; int ld32;
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
@@ -428,6 +439,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   const float* bias = p.bias ? p.bias + (long long)z * p.bsBias : nullptr;
   const T* mul = p.mul ? reinterpret_cast<const T*>(p.mul) + (long long)z * p.bsMul : nullptr;
   const float* res = p.res ? p.res + (long long)z * p.bsRes : nullptr;
+  const T* resT = reinterpret_cast<const T*>(p.resT);   // residual in the operand type (batch 1 only)
   float* out32 = p.out32 ? p.out32 + (long long)z * p.bs32 : nullptr;
   T* outT = p.outT ? reinterpret_cast<T*>(p.outT) + (long long)z * p.bsT : nullptr;
   const int act = ACT >= 0 ? ACT : p.act;
@@ -478,6 +490,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
               float4 v0 = *reinterpret_cast<const float4*>(stage + r * LDE + cc8);
               float4 v1 = *reinterpret_cast<const float4*>(stage + r * LDE + cc8 + 4);
               const int m = m0 + wm * (MI * 32) + mi * 32 + r;
+              float sq8 = 0.f;
               if (m < p.M && n8 < p.N) {
                 long long orow = m;
                 if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
@@ -489,9 +502,18 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
                   const float4 r0 = load4(res + (long long)m * p.ldres + n8), r1 = load4(res + (long long)m * p.ldres + n8 + 4);
                   v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
                 }
+                if (resT) {
+                  const float4 r0 = load4(resT + (long long)m * p.ldresT + n8), r1 = load4(resT + (long long)m * p.ldresT + n8 + 4);
+                  v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w; v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
+                }
                 uint4 o;
                 o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
                 *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
+                sq8 = sumsq8_bf16(o);
+              }
+              if (p.ssq_out) {   // statistics of the STORED (rounded) stream values; 4 lanes hold the 32 columns of a partial
+                sq8 += __shfl_xor(sq8, 1, 64); sq8 += __shfl_xor(sq8, 2, 64);
+                if ((lane & 3) == 0 && m < p.M && n8 < p.N) p.ssq_out[(long long)m * (p.N >> 5) + (n8 >> 5)] = sq8;
               }
             }
             continue;
@@ -508,6 +530,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
             if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
             if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+            if (resT) { const float4 r4 = load4(resT + (long long)m * p.ldresT + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
             if (out32) store4(out32 + orow * p.ld32 + n, v);
             if (outT) store4(outT + orow * p.ldT + n, v);
             sq = sumsq4(v);
@@ -552,6 +575,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           }
           if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w; }
           if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+          if (resT) { const float4 r4 = load4(resT + (long long)m * p.ldresT + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
           const float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (out32) store4(out32 + orow * p.ld32 + n, o);
           if (outT) store4(outT + orow * p.ldT + n, o);
@@ -565,6 +589,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             x = apply_act(x, act);
             if (mul) x *= Elem<T>::load(mul + (long long)m * p.ldmul + ne);
             if (res) x += res[(long long)m * p.ldres + ne];
+            if (resT) x += Elem<T>::load(resT + (long long)m * p.ldresT + ne);
             if (out32) out32[orow * p.ld32 + ne] = x;
             if (outT) Elem<T>::store(outT + orow * p.ldT + ne, x);
           }
@@ -586,6 +611,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // EPI specialises the epilogue at compile time (fewer live scalars / registers than the all-runtime form, which spilled):
 //   (0 = every feature a runtime flag: not instantiated) 1 bf16-only output, optional bias / fused-RMSNorm row scale
 //   2 bf16-only output x gate (`mul`: GEGLU)      3 residual add with fp32 (+ optional bf16) output, optional RMS partials
+//   4 residual stream carried in bf16 (`resT`): out = bf16(acc + bias + bf16 residual), optional RMS partials of the stored values
 template <int ACT, int EPI, bool W8 = false>
 __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(const GemmDev p) {
   using T = bf16_t;
@@ -798,12 +824,12 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
     auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
     float* stg = reinterpret_cast<float*>(smem + EPI_OFF + w * 4096);
-    constexpr bool WIDE8 = EPI == 1 || EPI == 2;                  // bf16-only output, 16-byte stores
+    constexpr bool WIDE8 = EPI == 1 || EPI == 2 || EPI == 4;      // bf16-only output, 16-byte stores
     const T* mul = EPI == 2 ? reinterpret_cast<const T*>(p.mul) : nullptr;
     const float* res = EPI == 3 ? p.res : nullptr;
     float* out32 = EPI == 3 ? p.out32 : nullptr;
     T* outT = reinterpret_cast<T*>(p.outT);
-    float* ssq_out = EPI == 3 ? p.ssq_out : nullptr;
+    float* ssq_out = (EPI == 3 || EPI == 4) ? p.ssq_out : nullptr;
     // the epilogue's per-lane address arithmetic is tile-invariant: hipcc would hoist it out of the tile loop and keep
     // (spill) it across the main loop. An opaque copy of the lane id pins it here.
     int elane = lane;
@@ -846,17 +872,18 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
         if (W8) asm volatile("" : "+v"(scol[ni][j].x), "+v"(scol[ni][j].y), "+v"(scol[ni][j].z), "+v"(scol[ni][j].w));
       }
     // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
-    constexpr bool AUX = EPI == 2 || EPI == 3;
+    constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4;
     const char* auxp = nullptr;
     long long aux_ld = 0;                                         // bytes per row
     if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
     if (EPI == 3) { auxp = reinterpret_cast<const char*>(res + (long long)mrow0 * p.ldres + ncol0); aux_ld = (long long)p.ldres * 4; }
+    if (EPI == 4) { auxp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.resT) + (long long)mrow0 * p.ldresT + ncol0); aux_ld = (long long)p.ldresT * 2; }
     f32x4_t aux[2][NIT];
     auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {
       const int mi = sl / NI, ni = sl % NI;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 2 ? 2 : 4);
+        const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 3 ? 4 : 2);
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
       }
     };
@@ -912,6 +939,14 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
             v[1].x *= __uint_as_float(g2 << 16); v[1].y *= __uint_as_float(g2 & 0xffff0000u);
             v[1].z *= __uint_as_float(g3 << 16); v[1].w *= __uint_as_float(g3 & 0xffff0000u);
           }
+          if constexpr (EPI == 4) {        // + residual carried in bf16: 8 values
+            const f32x4_t g = aux[sl & 1][it];
+            const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
+            v[0].x += __uint_as_float(g0 << 16); v[0].y += __uint_as_float(g0 & 0xffff0000u);
+            v[0].z += __uint_as_float(g1 << 16); v[0].w += __uint_as_float(g1 & 0xffff0000u);
+            v[1].x += __uint_as_float(g2 << 16); v[1].y += __uint_as_float(g2 & 0xffff0000u);
+            v[1].z += __uint_as_float(g3 << 16); v[1].w += __uint_as_float(g3 & 0xffff0000u);
+          }
           if constexpr (EPI == 3) {        // + residual: 4 fp32 values
             const f32x4_t r4 = aux[sl & 1][it];
             v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
@@ -920,6 +955,11 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
             uint4 o;
             o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
             *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+            if (EPI == 4 && ssq_out) {   // RMS partials of the stored (rounded) stream: 4 lanes hold the 32 columns of a slab row
+              float sq = sumsq8_bf16(o);
+              sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
+              if ((elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;
+            }
           } else {
             store4(out32 + m * p.ld32 + n, v[0]);
             if (outT) store4(outT + m * p.ldT + n, v[0]);
@@ -1048,16 +1088,19 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   // specialised epilogues for the combinations the policy uses; everything else takes the generic instantiation
   int epi = 0;
   if (a.rb == 0) {
-    if (d.wide8 && !a.mul && !a.res && !a.ssq_out) epi = 1;
-    else if (d.wide8 && a.mul && !a.res && !a.rs_ssq && !a.ssq_out) epi = 2;
-    else if (!d.wide8 && a.res && a.out32 && !a.mul && !a.rs_ssq) epi = 3;
+    if (d.wide8 && !a.mul && !a.res && !a.resT && !a.ssq_out) epi = 1;
+    else if (d.wide8 && a.mul && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
+    else if (!d.wide8 && a.res && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;
+    else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
   }
-  switch (a.act * 4 + epi) {
-    case ACT_NONE * 4 + 1: return launch_persistent_inst<ACT_NONE, 1>(d, grid, st);
-    case ACT_NONE * 4 + 3: return launch_persistent_inst<ACT_NONE, 3>(d, grid, st);
-    case ACT_RELU * 4 + 1: return launch_persistent_inst<ACT_RELU, 1>(d, grid, st);
-    case ACT_GELU * 4 + 2: return launch_persistent_inst<ACT_GELU, 2>(d, grid, st);
-    case ACT_QUICKGELU * 4 + 1: return launch_persistent_inst<ACT_QUICKGELU, 1>(d, grid, st);
+  if (a.resT && epi != 4) return -1;   // one-tile-per-workgroup kernel
+  switch (a.act * 8 + epi) {
+    case ACT_NONE * 8 + 1: return launch_persistent_inst<ACT_NONE, 1>(d, grid, st);
+    case ACT_NONE * 8 + 3: return launch_persistent_inst<ACT_NONE, 3>(d, grid, st);
+    case ACT_NONE * 8 + 4: return launch_persistent_inst<ACT_NONE, 4>(d, grid, st);
+    case ACT_RELU * 8 + 1: return launch_persistent_inst<ACT_RELU, 1>(d, grid, st);
+    case ACT_GELU * 8 + 2: return launch_persistent_inst<ACT_GELU, 2>(d, grid, st);
+    case ACT_QUICKGELU * 8 + 1: return launch_persistent_inst<ACT_QUICKGELU, 1>(d, grid, st);
     default: return -1;   // no specialised instantiation (the all-runtime form spills): one-tile-per-workgroup kernel
   }
 }
@@ -1076,7 +1119,7 @@ inline SplitPlan splitk_plan(const GemmArgs& a, bool is_bf16) {
   SplitPlan p{1, a.K};
   if (!gemm_splitk(a.tune) || a.w8) return p;
   const int bk = is_bf16 ? 64 : 32;
-  if (a.batch > 1 || a.M <= 0 || a.N <= 0 || a.K % bk || a.N % 4 || a.ssq_out || a.rb > 0) return p;
+  if (a.batch > 1 || a.M <= 0 || a.N <= 0 || a.K % bk || a.N % 4 || a.ssq_out || a.rb > 0 || a.resT) return p;
   const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const int slices = a.K / bk;
   if (tiles >= 128 || slices < 24) return p;   // measured: the second pass only pays from K = 1536 (bf16) on
@@ -1150,24 +1193,30 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
+  d.resT = a.resT; d.ldresT = a.ldresT;
+  if (a.resT && (a.res || a.batch > 1)) return (int)hipErrorInvalidValue;
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
   d.wscale = a.w8 ? a.wscale : nullptr;
-  if (a.ssq_out && (!a.out32 || a.batch > 1 || a.N % 32 != 0)) return (int)hipErrorInvalidValue;
+  if (a.ssq_out && ((!a.out32 && !a.outT) || a.batch > 1 || a.N % 32 != 0)) return (int)hipErrorInvalidValue;
   if (a.rs_ssq && a.rs_parts <= 0) return (int)hipErrorInvalidValue;
   d.mtiles = d.ntiles = 0;
   bool v = (a.N % 4 == 0);
   if (a.bias) v = v && aligned_to(a.bias, 16) && (a.bsBias % 4 == 0);
   if (a.mul) v = v && aligned_to(a.mul, 4 * es) && (a.ldmul % 4 == 0) && (a.bsMul % 4 == 0);
   if (a.res) v = v && aligned_to(a.res, 16) && (a.ldres % 4 == 0) && (a.bsRes % 4 == 0);
+  if (a.resT) v = v && aligned_to(a.resT, 4 * es) && (a.ldresT % 4 == 0);
   if (a.out32) v = v && aligned_to(a.out32, 16) && (a.ld32 % 4 == 0) && (a.bs32 % 4 == 0);
   if (a.outT) v = v && aligned_to(a.outT, 4 * es) && (a.ldT % 4 == 0) && (a.bsT % 4 == 0);
   if (a.w8 && !v) return (int)hipErrorInvalidValue;   // fp8 weights need the vector epilogue (16-byte aligned outputs)
   d.wide8 = 0;
   if constexpr (sizeof(T) == 2) {
     d.wide8 = (v && a.outT && !a.out32 && a.N % 8 == 0 && a.ldT % 8 == 0 && a.bsT % 8 == 0 && aligned_to(a.outT, 16) &&
-               (!a.mul || (a.ldmul % 8 == 0 && a.bsMul % 8 == 0 && aligned_to(a.mul, 16)))) ? 1 : 0;
+               (!a.mul || (a.ldmul % 8 == 0 && a.bsMul % 8 == 0 && aligned_to(a.mul, 16))) &&
+               (!a.resT || (a.ldresT % 8 == 0 && aligned_to(a.resT, 16)))) ? 1 : 0;
+    // RMS partials without the fp32 stream exist only in the 8-column layout (statistics of the stored bf16 values)
+    if (a.ssq_out && !a.out32 && !d.wide8) return (int)hipErrorInvalidValue;
   }
   if constexpr (sizeof(T) == 2) {
     // TileL when the 256x256 grid still fills the chip (>= ~1 workgroup per CU) and padding waste is small

@@ -39,6 +39,8 @@ struct GemmArgs {
   int ldmul = 0;
   const float* res = nullptr; // fp32 [M, ldres]  (may alias out32: each element is read then written by one thread)
   int ldres = 0;
+  const void* resT = nullptr; // the same residual term in the OPERAND type T [M, ldresT] (residual stream carried in T; may
+  int ldresT = 0;             // alias outT). At most one of res / resT.
   float* out32 = nullptr;
   int ld32 = 0;
   void* outT = nullptr;
@@ -79,6 +81,9 @@ int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 // in: fp32 rows of length E at row stride ldin; outputs optional.
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
+// the same with the input rows in the operand type T (residual stream carried in T)
+int launch_layernorm_T(const void* inT, long long ldin, const float* gamma, const float* beta, float eps, int rms, int rows,
+                       int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
 int launch_cast(const float* in, void* outT, long long n, bool is_bf16, hipStream_t st);
 // operand-type copy of fp32 rows + their sum of squares (entry point of the fused-RMSNorm chain): outT[r][:] = in[r][:],
 // ssq[r] = sum in[r][:]^2

@@ -161,6 +161,9 @@ struct VimaHandle {
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
   int vit_chunk = 16384;
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
+  int stream_T = 1;         // residual stream of the T5 stack carried in the operand type (bf16) instead of fp32 + bf16 copy:
+                            // 4 instead of 10 bytes of HBM traffic per element and residual GEMM; measured effect on the
+                            // logits 1.5e-4. 0 = fp32 stream (round-1 behaviour)
   int t5_fuse_rms = 1;      // T5 RMSNorms folded into the neighbouring GEMMs (statistics in the producer epilogue, row scale in the consumer)
   int op_bf16_out = 0;      // vima_op_linear: route the result through the operand-type output (tests the T store paths)
   int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
@@ -583,8 +586,8 @@ struct Run {
         // bytes = each operand / output / epilogue input once
       const double nb = a.batch > 0 ? a.batch : 1, es = (double)h->esz(), mn = (double)a.M * a.N;
       const double bytes = nb * ((double)a.M * a.K * es + (double)a.N * a.K * (a.w8 ? 1.0 : es) + (a.out32 ? mn * 4 : 0) + (a.outT ? mn * es : 0) +
-                                 (a.res ? mn * 4 : 0) + (a.mul ? mn * es : 0) + (a.ssq_out ? (double)a.M * (a.N / 32) * 4 : 0));
-      prof_begin((a.res && a.out32) ? 3 : 0, 2.0 * a.M * (double)a.N * a.K * nb, bytes);
+                                 (a.res ? mn * 4 : 0) + (a.resT ? mn * es : 0) + (a.mul ? mn * es : 0) + (a.ssq_out ? (double)a.M * (a.N / 32) * 4 : 0));
+      prof_begin(((a.res && a.out32) || a.resT) ? 3 : 0, 2.0 * a.M * (double)a.N * a.K * nb, bytes);
     }
     int e = launch_gemm(a, h->bf16, st);
     prof_end();
@@ -617,6 +620,15 @@ struct Run {
     if (err) return err;
     prof_begin(2, 0);
     int e = launch_layernorm(in, ldin, g, b, eps, rms, rows, E, out32, outT, h->bf16, st);
+    prof_end();
+    if (e) err = fail(std::string("layernorm launch failed: ") + hipGetErrorString((hipError_t)e), e);
+    return err;
+  }
+  int lnT(const void* inT, long long ldin, const float* g, const float* b, float eps, int rms, int rows, int E, float* out32,
+          void* outT) {
+    if (err) return err;
+    prof_begin(2, 0);
+    int e = launch_layernorm_T(inT, ldin, g, b, eps, rms, rows, E, out32, outT, h->bf16, st);
     prof_end();
     if (e) err = fail(std::string("layernorm launch failed: ") + hipGetErrorString((hipError_t)e), e);
     return err;
@@ -864,6 +876,21 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
   a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
   a.mode = ATTN_T5;
   R.attn(a, attn_impl);
+  if (R.h->stream_T) {
+    // The residual stream IS hT (operand type: bf16 in the bf16 / fp8w precisions, fp32 in the parity mode): hT = T(hT + ctx Wo^T)
+    // in place, RMS partials of the stored values -> ssA. The fp32 copy `x` is not maintained (4 instead of 10 bytes of HBM
+    // traffic per stream element and residual GEMM).
+    auto gemm_s = [&](const void* A, int lda, const Lin& W, float* ssq_out) {
+      GemmArgs g;
+      g.A = A; g.lda = lda; R.setW(g, W); g.M = rows; g.N = W.N; g.K = W.K; g.act = ACT_NONE;
+      g.resT = b.hT; g.ldresT = kT5Model; g.outT = b.hT; g.ldT = kT5Model; g.ssq_out = ssq_out;
+      return R.gemm(g);
+    };
+    gemm_s(b.ctx, kT5Model, Ly.o, b.ssA);
+    gemm(b.hT, kT5Model, Ly.wi_g, ACT_RELU, nullptr, nullptr, b.u, kT5FF, b.ssA, kParts, nullptr);
+    gemm_s(b.u, kT5FF, Ly.wo, b.ssB);
+    return b.ssB;
+  }
   // x += ctx Wo^T ; bf16 copy of the new x -> hT ; partial sums of its squares -> ssA
   gemm(b.ctx, kT5Model, Ly.o, ACT_NONE, x, x, b.hT, kT5Model, nullptr, 0, b.ssA);
   gemm(b.hT, kT5Model, Ly.wi_g, ACT_RELU, nullptr, nullptr, b.u, kT5FF, b.ssA, kParts, nullptr);
@@ -917,9 +944,13 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     }
     if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
   }
-  R.ln(x, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[0] * L, kT5Model, out32, outT);
+  const bool sT = fused && h->stream_T;   // the stream lives in buf[i].hT
+  if (sT) R.lnT(buf[0].hT, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[0] * L, kT5Model, out32, outT);
+  else R.ln(x, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[0] * L, kT5Model, out32, outT);
   if (dual) {
-    Rb.ln(x + off1 * kT5Model, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
+    if (sT) Rb.lnT(buf[1].hT, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
+                   out32 ? out32 + off1 * kT5Model : nullptr, outT ? R.offT(outT, off1 * kT5Model) : nullptr);
+    else Rb.ln(x + off1 * kT5Model, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
           out32 ? out32 + off1 * kT5Model : nullptr, outT ? R.offT(outT, off1 * kT5Model) : nullptr);
     if (Rb.err) return R.err = Rb.err;
     if (join_aux(R)) return R.err = 1;
@@ -1165,6 +1196,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "dual_stream") h->dual_stream = (int)value;
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
+  else if (k == "stream_T") h->stream_T = (int)value;
   else return fail("vima_set_option: unknown key " + k);
   return 0;
 }
