@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict
 // ViT token embed: x[m, t, :] = ln_pre( (t == 0 ? cls : patch[m, t-1]) + pos[t] )   (vit.py:176-180). W = 768 fixed.
 // One wave per token row.
 // ---------------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void vit_embed_kernel(const float* __restrict__ pre, const float* __restrict__ cls,
                                                          const float* __restrict__ pos, const float* __restrict__ g,
-                                                         const float* __restrict__ b, float* x, long long rows) {
+                                                         const float* __restrict__ b, float* x, T* xT, long long rows) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const float* __restrict_
     o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
     o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
     o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
-    *reinterpret_cast<float4*>(x + row * 768 + c) = o;
+    if (x) *reinterpret_cast<float4*>(x + row * 768 + c) = o;
+    if (xT) store4(xT + row * 768 + c, o);
   }
 }
 
@@ -457,10 +459,11 @@ int launch_patchify(const uint8_t* crops, void* outT, int M, bool is_bf16, hipSt
 }
 
 int launch_vit_embed(const float* pre, const float* cls, const float* pos, const float* g, const float* b, float* x,
-                     int M, hipStream_t st) {
+                     void* xT, int M, bool is_bf16, hipStream_t st) {
   if (M <= 0) return 0;
   const long long rows = (long long)M * 5;
-  hipLaunchKernelGGL(vit_embed_kernel, dim3(nblk(rows, 4)), dim3(256), 0, st, pre, cls, pos, g, b, x, rows);
+  if (is_bf16) hipLaunchKernelGGL(vit_embed_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, pre, cls, pos, g, b, x, (bf16_t*)xT, rows);
+  else hipLaunchKernelGGL(vit_embed_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, pre, cls, pos, g, b, x, (float*)xT, rows);
   return (int)hipGetLastError();
 }
 

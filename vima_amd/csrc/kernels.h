@@ -91,9 +91,9 @@ int launch_rms_stats(const float* in, int rows, int E, void* outT, float* ssq, b
 
 // uint8 crops [M,3,32,32] -> normalised patch matrix T [M*4, 768], k = c*256 + py*16 + px (conv1 weight order)
 int launch_patchify(const uint8_t* crops, void* outT, int M, bool is_bf16, hipStream_t st);
-// tokens = LN_pre(concat(cls, patches) + pos): pre fp32 [M*4,768] -> x fp32 [M*5,768]
+// tokens = LN_pre(concat(cls, patches) + pos): pre fp32 [M*4,768] -> x fp32 [M*5,768] and / or xT (operand type)
 int launch_vit_embed(const float* pre, const float* cls, const float* pos, const float* g, const float* b,
-                     float* x, int M, hipStream_t st);
+                     float* x, void* xT, int M, bool is_bf16, hipStream_t st);
 // first bbox-MLP layer: relu(W[768,4] . (bbox/[256,128,128,256]) + b) -> T [R,768]
 int launch_bbox_l1(const long long* bbox, const float* W, const float* b, void* outT, int R, int Nout,
                    bool is_bf16, hipStream_t st);

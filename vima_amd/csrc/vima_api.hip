@@ -672,7 +672,7 @@ int join_aux(Run& R) {
   return 0;
 }
 
-struct VitBuf { void* P; float* pre; float* x; void *hT, *qkv, *att, *u, *y; };
+struct VitBuf { void* P; float* pre; float* x; void *hT, *qkv, *att, *u, *y; void *xT, *cT; };   // xT / cT: stream in the operand type
 
 // ViT (vit.py:171-191) on internal crop rows [r0, r0+mc) -> cat[r0.., 0:768]
 void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int mc, const VitBuf& b, void* cat) {
@@ -687,30 +687,45 @@ void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int 
   }
   // conv1 as GEMM (vit.py:172), fp32 out
   R.linear(b.P, kVitW, h->vit.conv, mc * 4, ACT_NONE, nullptr, 0, nullptr, 0, b.pre, kVitW, nullptr, 0);
-  OTHER(R, launch_vit_embed(b.pre, h->vit.cls, h->vit.pos, h->vit.lnpre_g, h->vit.lnpre_b, b.x, mc, R.st), "vit_embed");
+  const bool sT = h->stream_T != 0;   // residual stream carried in the operand type (see t5_layer_fused)
+  OTHER(R, launch_vit_embed(b.pre, h->vit.cls, h->vit.pos, h->vit.lnpre_g, h->vit.lnpre_b, sT ? nullptr : b.x, sT ? b.xT : nullptr, mc,
+                            h->bf16, R.st), "vit_embed");
   const int rows = mc * 5;
   const bool prune = h->vit_prune_last != 0;
   float* x = b.x;
+  // y = x + A W^T + bias on the stream: fp32 (x in place) or operand type (xT in place)
+  auto residual = [&](const void* A, int lda, const Lin& L, int M, const float* res32, int ldres, float* out32, const void* resT,
+                      int ldresT, void* outT, int ldo) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; R.setW(g, L); g.M = M; g.N = L.N; g.K = L.K; g.bias = L.b;
+    if (sT) { g.resT = resT; g.ldresT = ldresT; g.outT = outT; g.ldT = ldo; }
+    else { g.res = res32; g.ldres = ldres; g.out32 = out32; g.ld32 = ldo; }
+    return R.gemm(g);
+  };
+  auto norm = [&](const float* in32, const void* inT, long long ldin, const float* g, const float* bb, int M, void* out) {
+    return sT ? R.lnT(inT, ldin, g, bb, 1e-5f, 0, M, kVitW, nullptr, out) : R.ln(in32, ldin, g, bb, 1e-5f, 0, M, kVitW, nullptr, out);
+  };
   for (int j = 0; j < kVitLayers - (prune ? 1 : 0); ++j) {
     auto& B = h->vit.blk[j];
-    R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
+    norm(x, b.xT, kVitW, B.ln1g, B.ln1b, rows, b.hT);
     R.linear(b.hT, kVitW, B.in_proj, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, b.qkv, 3 * kVitW);
     R.prof_begin(1, 4.0 * mc * kVitHeads * 25.0 * 32);
     int e = launch_vit_attn(b.qkv, b.att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
     R.prof_end();
     R.other(e, "vit_attn");
-    R.linear(b.att, kVitW, B.out_proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
-    R.ln(x, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
+    residual(b.att, kVitW, B.out_proj, rows, x, kVitW, x, b.xT, kVitW, b.xT, kVitW);
+    norm(x, b.xT, kVitW, B.ln2g, B.ln2b, rows, b.hT);
     R.linear(b.hT, kVitW, B.fc, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, 4 * kVitW);
-    R.linear(b.u, 4 * kVitW, B.proj, rows, ACT_NONE, nullptr, 0, x, kVitW, x, kVitW, nullptr, 0);
+    residual(b.u, 4 * kVitW, B.proj, rows, x, kVitW, x, b.xT, kVitW, b.xT, kVitW);
   }
   const float* xpost = x;        // rows ln_post reads (cls token of every crop)
+  const void* xpostT = b.xT;
   long long ld_post = 5 * kVitW;
   if (prune) {
     // Last block: ln_post only reads the cls row (vit.py:186), so everything after the K/V projection is computed
     // for the cls token only (identical values for that row; the other 4 rows of the block output are never read).
     auto& B = h->vit.blk[kVitLayers - 1];
-    R.ln(x, kVitW, B.ln1g, B.ln1b, 1e-5f, 0, rows, kVitW, nullptr, b.hT);
+    norm(x, b.xT, kVitW, B.ln1g, B.ln1b, rows, b.hT);
     GemmArgs kvg;   // K,V of all 5 tokens: in_proj rows [W, 3W)
     kvg.A = b.hT; kvg.lda = kVitW; R.setW(kvg, B.in_proj, kVitW);
     kvg.M = rows; kvg.N = 2 * kVitW; kvg.K = kVitW; kvg.bias = B.in_proj.b + kVitW; kvg.outT = b.qkv; kvg.ldT = 2 * kVitW;
@@ -723,15 +738,16 @@ void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int 
     int e = launch_vit_attn_cls(b.y, b.qkv, b.att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
     R.prof_end();
     R.other(e, "vit_attn_cls");
-    R.linear(b.att, kVitW, B.out_proj, mc, ACT_NONE, nullptr, 0, x, 5 * kVitW, b.pre, kVitW, nullptr, 0);   // xc = x_cls + attn
-    R.ln(b.pre, kVitW, B.ln2g, B.ln2b, 1e-5f, 0, mc, kVitW, nullptr, b.hT);
+    residual(b.att, kVitW, B.out_proj, mc, x, 5 * kVitW, b.pre, b.xT, 5 * kVitW, b.cT, kVitW);   // xc = x_cls + attn
+    norm(b.pre, b.cT, kVitW, B.ln2g, B.ln2b, mc, b.hT);
     R.linear(b.hT, kVitW, B.fc, mc, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, 4 * kVitW);
-    R.linear(b.u, 4 * kVitW, B.proj, mc, ACT_NONE, nullptr, 0, b.pre, kVitW, b.pre, kVitW, nullptr, 0);
+    residual(b.u, 4 * kVitW, B.proj, mc, b.pre, kVitW, b.pre, b.cT, kVitW, b.cT, kVitW);
     xpost = b.pre;
+    xpostT = b.cT;
     ld_post = kVitW;
   }
   // ln_post on the cls rows, then @ projection into cat[:, 0:768]   (vit.py:186-189)
-  R.ln(xpost, ld_post, h->vit.lnpost_g, h->vit.lnpost_b, 1e-5f, 0, mc, kVitW, nullptr, b.y);
+  norm(xpost, xpostT, ld_post, h->vit.lnpost_g, h->vit.lnpost_b, mc, b.y);
   R.linear(b.y, kVitW, h->vit.projection, mc, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0,
            R.offT(cat, (long long)r0 * 2 * kVitW), 2 * kVitW);
 }
@@ -762,6 +778,8 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
     vb[i].att = R.wsT((size_t)chunk * 5 * kVitW);
     vb[i].u = R.wsT((size_t)chunk * 5 * 4 * kVitW);
     vb[i].y = R.wsT((size_t)chunk * kVitW);
+    vb[i].xT = h->stream_T ? R.wsT((size_t)chunk * 5 * kVitW) : nullptr;
+    vb[i].cT = h->stream_T ? R.wsT((size_t)chunk * kVitW) : nullptr;
   }
   if (R.err) return R.err;
   Run Rb{h, h->aux};
