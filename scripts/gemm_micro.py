@@ -22,6 +22,7 @@ def main():
     pol.set_option("gemm_raster", int(os.environ.get("RASTER", "0")))
     pol.set_option("gemm_epi", int(os.environ.get("EPI", "1")))
     pol.set_option("op_bf16_out", int(os.environ.get("BF16OUT", "0")))   # 1: bf16-only output like most in-model GEMMs
+    pol.set_option("op_stream_T", int(os.environ.get("STREAMT", "0")))   # 1 (with RES=1): residual + output in bf16 (EPI 4)
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * 0.03
     out = torch.empty(M, N, device="cuda")

@@ -82,6 +82,42 @@ def test_linear_bf16_output_path(M, N, K, tile):
         pol.set_option("op_bf16_out", 0)
 
 
+@pytest.mark.parametrize("tile,persist", [(0, 1), (1, 1), (2, 0), (2, 1), (8, 1)])
+@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (512, 768, 768), (2816, 512, 3072), (64, 768, 768), (8, 768, 3072)])
+def test_linear_residual_stream_in_operand_type(M, N, K, tile, persist):
+    """The residual-stream form of the T5 / ViT residual GEMMs (round 2): out = bf16(A W^T [+ bias] + bf16 residual), residual
+    and output in the operand type (persistent EPI 4 for full 256-tiles, the 8-column LDS epilogue of the one-tile kernels
+    otherwise), against torch with the same rounding points."""
+    pol = bare_policy("bf16")
+    pol.set_option("gemm_tile", tile)
+    pol.set_option("gemm_persist", persist)
+    pol.set_option("op_stream_T", 1)
+    try:
+        g = torch.Generator().manual_seed(M + N + K + tile)
+        for use_b in (0, 1):
+            A = torch.randn(M, K, generator=g)
+            W = torch.randn(N, K, generator=g) * K ** -0.5
+            b = torch.randn(N, generator=g) if use_b else None
+            r = torch.randn(M, N, generator=g) * 3.0
+            ref = bf(A) @ bf(W).T
+            if b is not None:
+                ref = ref + b
+            ref = bf(ref + bf(r))
+            d = [None if t is None else t.cuda() for t in (A, W, b, None, r)]
+            out = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, 0,
+                                               ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            # identical up to one bf16 ulp where the fp32 sums differ in the last bits before rounding
+            assert max_rel(out, ref) < 6e-3, (use_b, max_rel(out, ref))
+            assert (out.cpu() != ref).float().mean().item() < 0.02
+    finally:
+        pol.set_option("gemm_tile", 0)
+        pol.set_option("gemm_persist", 1)
+        pol.set_option("op_stream_T", 0)
+
+
 @pytest.mark.parametrize("tile,persist", [(2, 0), (2, 1)])
 @pytest.mark.parametrize("M,N,K", [(520, 768, 768), (256, 256, 64), (1000, 1300, 3072), (77, 520, 1536), (300, 200, 128),
                                    (512, 768, 768), (2816, 512, 3072), (256, 256, 128)])   # full tiles: persistent kernel

@@ -166,6 +166,7 @@ struct VimaHandle {
                             // logits 1.5e-4. 0 = fp32 stream (round-1 behaviour)
   int t5_fuse_rms = 1;      // T5 RMSNorms folded into the neighbouring GEMMs (statistics in the producer epilogue, row scale in the consumer)
   int op_bf16_out = 0;      // vima_op_linear: route the result through the operand-type output (tests the T store paths)
+  int op_stream_T = 0;      // vima_op_linear: pass `res` in the operand type (resT) like the T5 / ViT residual GEMMs do
   int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
                             // GEMM epilogues) of one half overlap the MFMA-bound GEMM main loops of the other half
   hipStream_t aux = nullptr;
@@ -1213,6 +1214,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else if (k == "dual_stream") h->dual_stream = (int)value;
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
+  else if (k == "op_stream_T") h->op_stream_T = (int)value;
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
   else return fail("vima_set_option: unknown key " + k);
@@ -1648,7 +1650,14 @@ int vima_op_linear(VimaHandle* h, const float* A, const float* W, const float* b
   GemmArgs a;
   a.A = aT; a.lda = K; a.W = wT; a.ldw = K; a.M = M; a.N = N; a.K = K; a.bias = bias; a.act = act; a.mul = mT; a.ldmul = N;
   a.res = res; a.ldres = N;
-  if (h->op_bf16_out && h->bf16) {   // exercise the operand-type (bf16) output path, then widen
+  if (h->op_stream_T && res) {   // residual carried in the operand type (the T5 / ViT stream form): res -> T, added in the epilogue
+    void* rT = R.wsT((size_t)M * N);
+    if (R.err) return R.err;
+    if ((long long)M * N % 4) return fail("vima_op_linear: sizes must be multiples of 4");
+    OTHER(R, launch_cast(res, rT, (long long)M * N, h->bf16, R.st), "cast");
+    a.res = nullptr; a.resT = rT; a.ldresT = N;
+  }
+  if ((h->op_bf16_out || (h->op_stream_T && res)) && h->bf16) {   // exercise the operand-type (bf16) output path, then widen
     void* oT = R.wsT((size_t)M * N);
     if (R.err) return R.err;
     a.outT = oT; a.ldT = N;
