@@ -341,8 +341,8 @@ def main():
                 "ms_per_step": round(d["ms"], 3), "tflops": round(tf, 2), "algorithmic_gbs": round(gbs, 1),
                 "flop_per_byte": round(inten, 1), "algorithmic_mb_per_launch": round(d["bytes"] / max(d["launches"], 1) / 1e6, 1)}
 
-    k_res = klass(g3, "vima::gemm_persistent_kernel<ACT_NONE, EPI 3> (+ gemm_kernel fallbacks): GEMMs with the fp32-residual epilogue "
-                      "(T5 o / wo, ViT out_proj / c_proj, decoder): read fp32 residual, write fp32 stream + bf16 copy + RMS partials")
+    k_res = klass(g3, "vima::gemm_persistent_kernel<ACT_NONE, EPI 4 | EPI 3> (+ gemm_kernel fallbacks): the residual GEMMs (T5 o / wo and ViT "
+                      "out_proj / c_proj with the stream in bf16: read + write 2 B per element, RMS partials; decoder: fp32 stream)")
     k_plain = klass(g0, "vima::gemm_persistent_kernel<*, EPI 1|2> / vima::gemm_kernel: all other GEMM launches (bf16-only output)")
     dominant = k_res if g3["ms"] >= g0["ms"] else k_plain
     gemm_ms = g0["ms"] + g3["ms"]

@@ -600,16 +600,20 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 3) void attn_mfma4_kernel(const 
       m_run = m_new;
     }
     uint32_t pk[2][8];
-    float rs = 0.f;
+    // the subtraction of the running maximum and the row sum as PACKED fp32 operations (v_pk_add_f32: two elements per
+    // issue slot; exp2 itself is a quarter-rate transcendental and stays scalar)
+    const f32x2_t mm = {m_run, m_run};
+    f32x2_t rs2 = {0.f, 0.f};
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(x[sub][r] - m_run);
-        const float p1 = __builtin_amdgcn_exp2f(x[sub][r + 1] - m_run);
-        pk[sub][r >> 1] = pack2_bf16(p0, p1);
-        rs += p0 + p1;
+        const f32x2_t dlt = f32x2_t{x[sub][r], x[sub][r + 1]} - mm;
+        const f32x2_t pp = {__builtin_amdgcn_exp2f(dlt[0]), __builtin_amdgcn_exp2f(dlt[1])};
+        pk[sub][r >> 1] = pack2_bf16(pp[0], pp[1]);
+        rs2 += pp;
       }
+    float rs = rs2[0] + rs2[1];
     rs += __shfl_xor(rs, 32, 64);
     l_run += rs;
     mark(2);   // softmax
