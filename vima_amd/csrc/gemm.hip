@@ -439,7 +439,10 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   const float* bias = p.bias ? p.bias + (long long)z * p.bsBias : nullptr;
   const T* mul = p.mul ? reinterpret_cast<const T*>(p.mul) + (long long)z * p.bsMul : nullptr;
   const float* res = p.res ? p.res + (long long)z * p.bsRes : nullptr;
-  const T* resT = reinterpret_cast<const T*>(p.resT);   // residual in the operand type (batch 1 only)
+  // residual in the operand type (batch 1 only): residual GEMMs have no activation, so the activation instantiations
+  // (GELU's erf is register-hungry: the extra live values spilled there) do not carry this code
+  constexpr bool kStreamEpi = ACT == ACT_NONE || ACT == -1;
+  const T* resT = kStreamEpi ? reinterpret_cast<const T*>(p.resT) : nullptr;
   float* out32 = p.out32 ? p.out32 + (long long)z * p.bs32 : nullptr;
   T* outT = p.outT ? reinterpret_cast<T*>(p.outT) + (long long)z * p.bsT : nullptr;
   const int act = ACT >= 0 ? ACT : p.act;
@@ -509,9 +512,9 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
                 uint4 o;
                 o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
                 *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
-                sq8 = sumsq8_bf16(o);
+                if (kStreamEpi) sq8 = sumsq8_bf16(o);
               }
-              if (p.ssq_out) {   // statistics of the STORED (rounded) stream values; 4 lanes hold the 32 columns of a partial
+              if (kStreamEpi && p.ssq_out) {   // statistics of the STORED (rounded) stream values; 4 lanes hold the 32 columns of a partial
                 sq8 += __shfl_xor(sq8, 1, 64); sq8 += __shfl_xor(sq8, 2, 64);
                 if ((lane & 3) == 0 && m < p.M && n8 < p.N) p.ssq_out[(long long)m * (p.N >> 5) + (n8 >> 5)] = sq8;
               }
@@ -1194,7 +1197,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
   d.resT = a.resT; d.ldresT = a.ldresT;
-  if (a.resT && (a.res || a.batch > 1)) return (int)hipErrorInvalidValue;
+  if (a.resT && (a.res || a.batch > 1 || a.act != ACT_NONE)) return (int)hipErrorInvalidValue;
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
