@@ -122,7 +122,7 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
                       "NOT in the timed port: the reference's O(B*Lp) Python prompt-assembly loop (vima_policy.py:168-233; the "
                       "oracle assembles with index ops) and its DataDict plumbing. /root/reference does not exist on the GPU box, so "
                       "the shimmed reference cannot be timed there; in the build container (8 cores, batch 4, same workload) the "
-                      "unmodified reference ran at 3.8 and this port at 3.2 samples/s (profiles/r02_cpu_reference_vs_port.json)",
+                      "unmodified reference and this port run within 15 % of each other (4.2 vs 4.1 samples/s, profiles/r02_cpu_reference_vs_port.json)",
             "usable_cores": ncores, "host_cpu_count": os.cpu_count(), "threads_tried": cands}
 
 
