@@ -256,9 +256,26 @@ def main():
 
     from vima_amd import synthetic as syn, parallel
     from vima_amd.policy import VIMAPolicy
+    collective = None
     if world > 1:
-        comm = parallel.LogitsComm(dev)                # RCCL communicator behind the C ABI (vima_allgather_logits)
-        assert comm.world == world
+        # RCCL communicator behind the C ABI (vima_allgather_logits). Every rank must take the same path: agree on success
+        # through the torch.distributed group; if any rank failed to create it, all fall back to torch.distributed's own
+        # all-gather (also RCCL) and the line says so.
+        err = ""
+        try:
+            comm = parallel.LogitsComm(dev)
+            assert comm.world == world
+        except Exception as e:   # noqa: BLE001
+            comm, err = None, f"{type(e).__name__}: {e}"
+        ok = torch.tensor([0 if comm is None else 1], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            collective = "vima_allgather_logits (C ABI, RCCL)"
+        else:
+            if comm is not None:
+                comm.close()
+            comm = None
+            collective = f"torch.distributed all_gather_into_tensor (RCCL); C-ABI communicator unavailable on some rank: {err or 'other rank'}"
 
     Q = 2 * args.qv
     seg_len = args.words + Q                         # words + 1 image (Q object tokens) per segment
@@ -378,7 +395,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"VIMA-{args.model} COLD policy forward (prompt assembly ViT+T5, obs ViT, XAttnGPT, action head) "
                                    f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [{args.words} words + 1 image]), {Q} object tokens/obs, T={T}",
-                       "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}",
+                       "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}", "collective": collective,
                        "samples_per_s": round(world * B * args.steps / dt, 1),
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),
                        "warm_ms_per_step": round(warm_ms, 3) if warm_ms == warm_ms else None, "warm_steps_per_s": round(world * 1e3 / warm_ms, 2) if warm_ms == warm_ms else None,
@@ -389,7 +406,8 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
-        comm.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 
