@@ -66,3 +66,27 @@ def test_fp8w_weight_bytes_and_small_layers_stay_bf16():
     b16, b8 = free0 - free1, free1 - free2
     table = 32128 * 768 * 4
     assert b8 < b16 and (b8 - table) < 0.62 * (b16 - table), (b16, b8)
+
+
+def test_fp8w_incremental_decoding_and_kv_cache():
+    """The episode-cache entry points (vima_decode_step, prompt K/V cache) in the fp8w precision: step-by-step decoding
+    reproduces the re-fed history, cached and stateless forward agree bit for bit."""
+    cfg = syn.config("20M")
+    sd = syn.make_state_dict(cfg, 11)
+    pol = loaded_policy(cfg, sd, "fp8w")
+    ref = loaded_policy(cfg, sd, "fp8w")
+    ref.cache_prompt_kv = False
+    g = torch.Generator().manual_seed(5)
+    B, Lp, Q, E, T = 3, 24, 8, cfg.embed_dim, 4
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = torch.ones(B, Lp, dtype=torch.bool)
+    pmask[1, 17:] = False
+    otok = torch.randn(T, B, Q, E, generator=g).to(DEV)
+    omask = torch.ones(T, B, Q, dtype=torch.bool)
+    atok = torch.randn(T - 1, B, E, generator=g).to(DEV)
+    full = pol.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV))
+    assert torch.equal(pol.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV)), full)          # cached K/V
+    assert torch.equal(ref.forward(otok, omask.to(DEV), atok, ptok, pmask.to(DEV)), full)          # stateless
+    for t in range(T):
+        step = pol.forward_step(otok[t], omask[t], atok[t - 1] if t > 0 else None, ptok, pmask, t)
+        assert max_rel(step, full[t]) < 4e-2, (t, max_rel(step, full[t]))

@@ -439,6 +439,33 @@ def test_graph_replay_is_exact(prec):
         assert torch.equal(a, b)
 
 
+def test_prompts_with_only_images_and_without_images():
+    """Degenerate prompt compositions: a prompt made only of images (against the oracle), and a batch whose prompts are
+    pure words -- the reference cannot run that one (`img.max()` of an empty image batch raises inside
+    basic_image_tensor_preprocess, preprocess.py:28), the native path skips the object encoder: finite tokens, all-True mask,
+    and the word rows equal those of a mixed prompt's T5 input up to attention (checked through determinism only)."""
+    cfg = syn.config("4M")
+    sd = syn.make_state_dict(cfg, 9)
+    orc = OraclePolicy(sd, **cfg.ctor_kwargs())
+    obs = syn.make_obs(1, 2, 2, seed=52)
+    prompts = syn.make_prompt(2, layout=[[1, 1], [1, 0]], q_per_view=2, seed=51)
+    o, od = run_policy(orc, prompts, obs, None)
+    ref_logits = torch.cat([od[k]["raw"] for k in ACTION_KEYS], dim=-1)
+    for prec, tol in (("fp32", 2e-5), ("bf16", 1e-3)):
+        pol = loaded_policy(cfg, sd, prec)
+        out = native_outputs(pol, prompts, obs, None)
+        assert torch.equal(out["prompt_masks"].cpu(), o["prompt_masks"])
+        assert max_abs(out["raw_logits"], ref_logits) < tol, (prec, max_abs(out["raw_logits"], ref_logits))
+        assert max_rel(out["prompt_tokens"], o["prompt_tokens"]) < (2e-4 if prec == "fp32" else 4e-2)
+    words_only = syn.make_prompt(2, layout=[[0, 0, 0], [0, 0, 0, 0, 0]], q_per_view=2, seed=51)
+    pol = loaded_policy(cfg, sd, "bf16")
+    ptok, pmask = pol.forward_prompt_assembly(syn.to_device(words_only, DEV))
+    assert ptok.shape == (5, 2, cfg.embed_dim) and torch.isfinite(ptok).all()
+    assert pmask.cpu().tolist() == [[True, True, True, False, False], [True] * 5]
+    ptok2, _ = pol.forward_prompt_assembly(syn.to_device(words_only, DEV))
+    assert torch.equal(ptok, ptok2)
+
+
 def test_create_policy_from_ckpt_round_trip(tmp_path):
     """write a checkpoint file with the reference's layout ({"cfg": ctor kwargs, "state_dict":
     {"policy.<key>": tensor}}, vima/__init__.py:9-14), load it with vima_amd.create_policy_from_ckpt and compare with a

@@ -102,6 +102,29 @@ def test_batch_of_bench_size_and_prepare_obs_into_the_policy():
     assert torch.equal(msk[:, 0].cpu(), torch.cat([torch.from_numpy(want["mask"]["front"]), torch.from_numpy(want["mask"]["top"])], dim=-1))
 
 
+def test_edge_cases_full_frame_object_empty_batch_and_duplicate_ids():
+    """An object covering the whole 128 x 256 frame (S = 256: integer factor 8 with 64 rows of zero padding above / below),
+    a frame without any listed object (all slots padded), duplicated ids, and an empty batch."""
+    g = np.random.default_rng(3)
+    H, W = 128, 256
+    rgb = g.integers(0, 256, size=(3, 3, H, W), dtype=np.uint8)
+    segm = np.zeros((3, H, W), dtype=np.uint8)
+    segm[0, :, :] = 9                       # full frame
+    segm[1, 3:5, 4:6] = 2                   # only an id that is NOT asked for
+    segm[2, 10:40, 10:60] = 9
+    ids = [9, 7, 9]                         # id 9 twice: both slots carry the same object (np.nonzero per id in the reference)
+    crops, bbox, mask = preprocess.crop_objects(torch.from_numpy(rgb), torch.from_numpy(segm), ids, device=DEV)
+    for i in range(3):
+        c, b, m = crop_objects_view(rgb[i], segm[i], ids)
+        assert np.array_equal(mask[i].cpu().numpy(), m), (i, m)
+        assert np.array_equal(bbox[i].cpu().numpy(), b) and np.array_equal(crops[i].cpu().numpy(), c), i
+    assert mask[0].tolist() == [True, True, False] and mask[1].tolist() == [False, False, False]
+    assert bbox[0, 0].tolist() == [127, 63, 127, 255]
+    assert (crops[1] == 0).all()
+    e_c, e_b, e_m = preprocess.crop_objects(torch.zeros(0, 3, H, W, dtype=torch.uint8), torch.zeros(0, H, W, dtype=torch.uint8), [1, 2], device=DEV)
+    assert e_c.shape == (0, 2, 3, 32, 32) and e_b.shape == (0, 2, 4) and e_m.shape == (0, 2)
+
+
 def test_argument_errors():
     with pytest.raises(AssertionError):
         preprocess.crop_objects(torch.zeros(1, 3, 8, 8), torch.zeros(1, 8, 8, dtype=torch.uint8), [1], device=DEV)     # float rgb
