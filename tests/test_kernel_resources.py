@@ -45,3 +45,60 @@ def test_hot_kernels_use_no_scratch(src, patterns):
         allowed = 32 if "gemm_persistent_kernelILi2ELi2ELb1" in k else 0
         assert v.get("ScratchSize", 0) <= allowed, (k, v)
         assert v.get("VGPRs", 0) + v.get("AGPRs", 0) <= 256, (k, v)     # two waves per SIMD for the 512-thread GEMMs
+
+
+def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
+    """The persistent GEMM's epilogue prefetches its per-row operand (residual / gate) with inline-asm loads that hipcc does
+    not track; the destination VGPRs count as written at the asm statement, so the compiler could legally read, copy or reuse
+    them before the data lands (guide: cdna_hip_programming.md 5.7 item 1). This audits the generated ISA: between an asm
+    `global_load_dwordx4` and the counted `s_waitcnt` that covers it, no other instruction may name those registers. Loads
+    are issued one slab ahead, so at every wait the batch issued right before it stays in flight and all older ones retire."""
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
+                          "--cuda-device-only", "-S", os.path.join(ROOT, "vima_amd", "csrc", "gemm.hip"), "-o", "-"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    src = out.stdout
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    checked = 0
+    for m in re.finditer(r"^(_ZN4vima\S*gemm_persistent_kernelILi\dELi([234])ELb[01]EEE\S*):", src, flags=re.M):
+        body = src[m.end():src.index("s_endpgm", m.end())].split("\n")
+        nit = 4 if m.group(2) == "3" else 2        # loads per slab: fp32 residual 4 row groups, gate / bf16 residual 2
+        pending, in_asm, loads, since_wait = [], False, 0, 0
+        for line in body:
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            toks = re.split(r"[\s,]+", t)
+            if in_asm and toks[0] == "global_load_dwordx4":
+                pending.append(regs(toks[1]))
+                loads += 1
+                since_wait += 1
+                continue
+            if in_asm and toks[0] == "s_waitcnt":
+                # VMEM retires in order: everything but the youngest `nit` loads (the next slab's, issued right before this
+                # wait) has landed; on the last slab nothing was issued since the previous wait and everything has landed
+                pending = pending[-nit:] if since_wait else []
+                since_wait = 0
+                continue
+            if not in_asm and pending:
+                inflight = set().union(*pending)
+                used = set()
+                for tk in toks[1:]:
+                    used |= regs(tk)
+                assert not (used & inflight), (m.group(1), t, sorted(used & inflight)[:4])
+        assert loads in (16, 32), (m.group(1), loads)
+        checked += 1
+    assert checked >= 6, checked
