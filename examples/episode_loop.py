@@ -2,10 +2,13 @@
 the VIMA-Bench simulator (not installable offline): prompt encoded once per episode, then per env step
 observation tokens -> decoder -> action distribution -> embedded action for the next step.
 
-    python examples/episode_loop.py [--model 200M] [--batch 1] [--steps 8] [--refeed]
+    python examples/episode_loop.py [--model 200M] [--batch 1] [--steps 8] [--refeed] [--frames]
 
 --refeed reproduces the reference loop literally (the whole history goes through `forward` every step); the default
 uses `forward_step`, which processes only the newest tokens against the episode caches and gives the same predictions.
+--frames starts every env step from raw camera frames + segmentation maps (what env.step() returns in the reference) and
+runs the GPU image preprocessing (`vima_amd.preprocess.prepare_obs` -> vima_crop_objects: mask -> bbox -> crop -> 32x32
+INTER_AREA) instead of feeding ready-made crops; batch 1 like the reference loop.
 """
 import argparse
 import os
@@ -25,7 +28,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--refeed", action="store_true")
+    ap.add_argument("--frames", action="store_true")
     args = ap.parse_args()
+    if args.frames:
+        args.batch = 1
     dev = "cuda:0"
     cfg = syn.config(args.model, xattn_n_positions=512)
     policy = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision="bf16", device=dev)
@@ -33,7 +39,15 @@ def main():
     B = args.batch
     prompt = syn.to_device(syn.make_prompt(B, n_segments=32, words_per_segment=8, q_per_view=4, seed=1), dev)
     prompt_tokens, prompt_masks = policy.forward_prompt_assembly(prompt)          # once per episode
-    observations = [syn.to_device(syn.make_obs(1, B, 4, seed=100 + t), dev) for t in range(args.steps)]   # stands in for env.step()
+    if args.frames:     # raw 128 x 256 frames + segmentation of 4 objects per view, as env.step() returns them
+        from oracle.preprocess_oracle import synthetic_frames      # (synthetic data generator only)
+        observations = []
+        for t in range(args.steps):
+            fr = {v: synthetic_frames(1, 4, seed=100 + 2 * t + i) for i, v in enumerate(("front", "top"))}
+            observations.append({"ee": torch.tensor([t % 2]), "rgb": {v: torch.from_numpy(fr[v][0]).to(dev) for v in fr},
+                                 "segm": {v: torch.from_numpy(fr[v][1]).to(dev) for v in fr}, "ids": fr["front"][2]})
+    else:
+        observations = [syn.to_device(syn.make_obs(1, B, 4, seed=100 + t), dev) for t in range(args.steps)]   # stands in for env.step()
     for episode in range(2):                                                      # episode 0 warms up (workspace, caches)
         ms = run_episode(policy, args, observations, prompt_tokens, prompt_masks)
     print(ms)
@@ -46,6 +60,11 @@ def run_episode(policy, args, observations, prompt_tokens, prompt_masks):
     t0 = time.perf_counter()
     for t in range(args.steps):
         obs = observations[t]
+        if args.frames:                                                           # prepare_obs (example.py:374-473) on the GPU
+            from vima_amd.preprocess import prepare_obs
+            meta = {"n_objects": len(obs["ids"]), "obj_id_to_info": {i: {} for i in obs["ids"]}}
+            obs = prepare_obs(obs={"ee": obs["ee"], "rgb": dict(obs["rgb"]), "segm": dict(obs["segm"])}, rgb_dict=None, meta=meta,
+                              device=policy._device)
         obs_token, obs_mask = policy.forward_obs_token(obs)                       # [1,B,Q,E], [1,B,Q]
         if args.refeed:
             obs_cache.append((obs_token, obs_mask))

@@ -1,9 +1,10 @@
 // Image preprocessing in front of the policy, on the GPU: the per-object work of `prepare_obs` /
 // `prepare_prompt` (/root/reference/scripts/example.py:243-473) -- segmentation mask -> pixel bbox -> inclusive crop ->
 // zero-pad to a square -> cv2.resize(32x32, INTER_AREA) -> uint8 -- for every (frame, object id) at once.
-// Integer / byte work, HBM-trivial (a 128x256 frame is 128 KiB): one workgroup per frame scans the mask once (LDS
-// min/max/count per object), orders the objects like the reference (present ones first, missing ones zero-padded at
-// the end, mask False) and resamples each crop straight from the frame. The three resize regimes follow OpenCV's
+// Integer / byte work, HBM-trivial (a 128x256 frame is 128 KiB): one workgroup per (frame, output slot) scans the mask (LDS
+// min/max/count per object id; the scan is repeated by the n_obj workgroups of a frame -- 32 KiB each, cheaper than a
+// second launch), orders the objects like the reference (present ones first, missing ones zero-padded at the end, mask
+// False) and resamples ITS crop straight from the frame. The three resize regimes follow OpenCV's
 // documented arithmetic exactly (oracle/preprocess_oracle.py restates them; results are compared bit for bit):
 //   S % 32 == 0 : block sums; 2x2 -> (sum + 2) >> 2, else rint(sum * (1.f / f^2))   (resizeAreaFast_)
 //   S > 32      : separable fp32 area weights, adds in table order, no fma          (computeResizeAreaTab / ResizeArea_Invoker)
@@ -50,8 +51,10 @@ template <typename SegT>
 __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __restrict__ rgb, const SegT* __restrict__ segm,
                                                            const int* __restrict__ obj_ids, int n_obj, int H, int W,
                                                            uint8_t* __restrict__ crops, long long* __restrict__ bbox,
-                                                           uint8_t* __restrict__ mask) {
-  __shared__ int s_id[kMaxObj], s_xmin[kMaxObj], s_xmax[kMaxObj], s_ymin[kMaxObj], s_ymax[kMaxObj], s_cnt[kMaxObj];
+                                                           uint8_t* __restrict__ mask, int lds_bytes) {
+  extern __shared__ uint8_t s_crop[];   // the crop's source pixels [3][hc][wc] (when they fit): every tap then reads LDS
+  __shared__ int s_id[kMaxObj];
+  __shared__ volatile int s_xmin[kMaxObj], s_xmax[kMaxObj], s_ymin[kMaxObj], s_ymax[kMaxObj], s_cnt[kMaxObj];
   __shared__ int s_slot_obj[kMaxObj];   // slot -> object index (present objects in order), -1 = padding
   __shared__ Taps s_taps[kOut];
   __shared__ int s_lofs[kOut], s_lc0[kOut], s_lc1[kOut];
@@ -70,9 +73,13 @@ __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __rest
     for (int k = 0; k < n_obj; ++k) {
       if (v == s_id[k]) {   // ids may repeat in obj_ids: every matching entry sees the pixel
         const int y = p / W, x = p - y * W;
-        atomicMin(&s_xmin[k], x); atomicMax(&s_xmax[k], x);
-        atomicMin(&s_ymin[k], y); atomicMax(&s_ymax[k], y);
-        atomicAdd(&s_cnt[k], 1);
+        // plain reads only FILTER the atomics (a stale value costs one redundant atomic, never a wrong extent); the count is
+        // only ever compared with 2
+        if (x < s_xmin[k]) atomicMin((int*)&s_xmin[k], x);
+        if (x > s_xmax[k]) atomicMax((int*)&s_xmax[k], x);
+        if (y < s_ymin[k]) atomicMin((int*)&s_ymin[k], y);
+        if (y > s_ymax[k]) atomicMax((int*)&s_ymax[k], y);
+        if (s_cnt[k] < 2) atomicAdd((int*)&s_cnt[k], 1);
       }
     }
   }
@@ -85,7 +92,8 @@ __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __rest
     for (; slot < n_obj; ++slot) s_slot_obj[slot] = -1;
   }
   __syncthreads();
-  for (int slot = 0; slot < n_obj; ++slot) {
+  {   // one workgroup per (frame, slot): every workgroup of a frame repeats the (cheap) mask scan, then resamples its own crop
+    const int slot = blockIdx.y;
     const int k = s_slot_obj[slot];   // workgroup-uniform
     uint8_t* out = crops + (f * n_obj + slot) * 3LL * kOut * kOut;
     long long* bb = bbox + (f * n_obj + slot) * 4;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __rest
       for (int i = tid; i < 3 * kOut * kOut; i += 256) out[i] = 0;
       if (tid < 4) bb[tid] = 0;
       if (tid == 0) mask[f * n_obj + slot] = 0;
-      continue;
+      return;
     }
     const int xmin = s_xmin[k], xmax = s_xmax[k], ymin = s_ymin[k], ymax = s_ymax[k];
     const int hc = ymax - ymin + 1, wc = xmax - xmin + 1;
@@ -107,16 +115,24 @@ __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __rest
     const int S = hc > wc ? hc : wc;
     const int padx = hc > wc ? (hc - wc) / 2 : 0;   // zeros BEFORE the crop on the shorter axis (example.py:411-413)
     const int pady = wc > hc ? (wc - hc) / 2 : 0;
-    // square-source pixel (c, sy, sx) -> frame pixel or the zero padding
+    // stage the crop's pixels in LDS (coalesced row reads); a crop of a frame larger than the LDS budget is read in place
+    const bool staged = 3 * hc * wc <= lds_bytes;
+    if (staged) {
+      for (int i = tid; i < 3 * hc * wc; i += 256) {
+        const int c = i / (hc * wc), r = i - c * hc * wc, yy = r / wc, xx = r - yy * wc;
+        s_crop[i] = img[((long long)c * H + (ymin + yy)) * W + (xmin + xx)];
+      }
+    }
+    // square-source pixel (c, sy, sx) -> crop pixel or the zero padding
     auto src = [&](int c, int sy, int sx) -> int {
       const int yy = sy - pady, xx = sx - padx;
       if (yy < 0 || yy >= hc || xx < 0 || xx >= wc) return 0;
+      if (staged) return (int)s_crop[(c * hc + yy) * wc + xx];
       return (int)img[((long long)c * H + (ymin + yy)) * W + (xmin + xx)];
     };
     const bool integer_scale = S >= kOut && S % kOut == 0;
     const bool up = S < kOut;
     const bool tabbed = !integer_scale && !up;
-    __syncthreads();   // previous slot's tables are no longer read
     if (tid < kOut) {
       if (up) {
         const double scale = (double)S / kOut, inv = 1.0 / scale;
@@ -179,12 +195,21 @@ extern "C" int vima_crop_objects(const uint8_t* rgb, const void* segm, int segm_
     return vima::api_fail("vima_crop_objects: frame sides must be in [1, 320] (VIMA-Bench frames are 128 x 256)");
   if (segm_elem_bytes != 1 && segm_elem_bytes != 4) return vima::api_fail("vima_crop_objects: segm must be uint8 or int32");
   hipStream_t st = (hipStream_t)stream;
+  long long need = 3LL * H * W;
+  const int lds = (int)(need < 96 * 1024 ? need : 96 * 1024);   // a whole 128 x 256 frame fits; larger frames: crops up to 96 KiB
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_objects_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_objects_kernel<int>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+      return vima::api_fail("vima_crop_objects: hipFuncSetAttribute failed");
+    attr_done = true;
+  }
   if (segm_elem_bytes == 1)
-    hipLaunchKernelGGL(crop_objects_kernel<uint8_t>, dim3((unsigned)n_frames), dim3(256), 0, st, rgb, (const uint8_t*)segm, obj_ids,
-                       n_obj, H, W, crops, (long long*)bbox, mask);
+    hipLaunchKernelGGL(crop_objects_kernel<uint8_t>, dim3((unsigned)n_frames, (unsigned)n_obj), dim3(256), (size_t)lds, st, rgb, (const uint8_t*)segm, obj_ids,
+                       n_obj, H, W, crops, (long long*)bbox, mask, lds);
   else
-    hipLaunchKernelGGL(crop_objects_kernel<int>, dim3((unsigned)n_frames), dim3(256), 0, st, rgb, (const int*)segm, obj_ids, n_obj, H,
-                       W, crops, (long long*)bbox, mask);
+    hipLaunchKernelGGL(crop_objects_kernel<int>, dim3((unsigned)n_frames, (unsigned)n_obj), dim3(256), (size_t)lds, st, rgb, (const int*)segm, obj_ids, n_obj, H,
+                       W, crops, (long long*)bbox, mask, lds);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vima::api_fail(std::string("vima_crop_objects launch failed: ") + hipGetErrorString(e));
   return 0;
