@@ -67,19 +67,27 @@ __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __rest
     s_xmin[tid] = W; s_xmax[tid] = -1; s_ymin[tid] = H; s_ymax[tid] = -1; s_cnt[tid] = 0;
   }
   __syncthreads();
-  // ---- pass 1: per-object pixel extent and count (np.nonzero(segm == obj_id), example.py:400)
-  for (int p = tid; p < H * W; p += 256) {
-    const int v = (int)sg[p];
-    for (int k = 0; k < n_obj; ++k) {
-      if (v == s_id[k]) {   // ids may repeat in obj_ids: every matching entry sees the pixel
-        const int y = p / W, x = p - y * W;
-        // plain reads only FILTER the atomics (a stale value costs one redundant atomic, never a wrong extent); the count is
-        // only ever compared with 2
-        if (x < s_xmin[k]) atomicMin((int*)&s_xmin[k], x);
-        if (x > s_xmax[k]) atomicMax((int*)&s_xmax[k], x);
-        if (y < s_ymin[k]) atomicMin((int*)&s_ymin[k], y);
-        if (y > s_ymax[k]) atomicMax((int*)&s_ymax[k], y);
-        if (s_cnt[k] < 2) atomicAdd((int*)&s_cnt[k], 1);
+  // ---- pass 1: per-object pixel extent and count (np.nonzero(segm == obj_id), example.py:400). Only a handful of
+  // workgroups run, so nothing hides a load's latency: every thread fetches 8 pixels (independent loads) before it looks at them
+  for (int p0 = tid * 8; p0 < H * W; p0 += 256 * 8) {
+    int vals[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vals[j] = p0 + j < H * W ? (int)sg[p0 + j] : -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int v = vals[j], p = p0 + j;
+      if (p >= H * W) break;
+      for (int k = 0; k < n_obj; ++k) {
+        if (v == s_id[k]) {   // ids may repeat in obj_ids: every matching entry sees the pixel
+          const int y = p / W, x = p - y * W;
+          // plain reads only FILTER the atomics (a stale value costs one redundant atomic, never a wrong extent); the count
+          // is only ever compared with 2
+          if (x < s_xmin[k]) atomicMin((int*)&s_xmin[k], x);
+          if (x > s_xmax[k]) atomicMax((int*)&s_xmax[k], x);
+          if (y < s_ymin[k]) atomicMin((int*)&s_ymin[k], y);
+          if (y > s_ymax[k]) atomicMax((int*)&s_ymax[k], y);
+          if (s_cnt[k] < 2) atomicAdd((int*)&s_cnt[k], 1);
+        }
       }
     }
   }
@@ -118,9 +126,38 @@ __global__ __launch_bounds__(256) void crop_objects_kernel(const uint8_t* __rest
     // stage the crop's pixels in LDS (coalesced row reads); a crop of a frame larger than the LDS budget is read in place
     const bool staged = 3 * hc * wc <= lds_bytes;
     if (staged) {
-      for (int i = tid; i < 3 * hc * wc; i += 256) {
-        const int c = i / (hc * wc), r = i - c * hc * wc, yy = r / wc, xx = r - yy * wc;
-        s_crop[i] = img[((long long)c * H + (ymin + yy)) * W + (xmin + xx)];
+      // row-wise copy (no per-byte index divisions): wave w takes crop rows w, w + 4, ... of the 3 * hc (channel, row) pairs,
+      // four rows per trip so that up to 16 independent loads are in flight per lane
+      const int wv = tid >> 6, ln = tid & 63;
+      for (int r0 = wv * 4; r0 < 3 * hc; r0 += 16) {
+        uint8_t px[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = r0 + j;
+          if (row < 3 * hc) {
+            const int c = row / hc, yy = row - c * hc;
+            const uint8_t* g = img + ((long long)c * H + (ymin + yy)) * W + xmin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (ln + q * 64 < wc) px[j][q] = g[ln + q * 64];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = r0 + j;
+          if (row < 3 * hc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (ln + q * 64 < wc) s_crop[row * wc + ln + q * 64] = px[j][q];
+          }
+        }
+        for (int xx = 256 + ln; xx < wc; xx += 64)      // frames wider than 256 px (up to 320)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (r0 + j < 3 * hc) {
+              const int row = r0 + j, c = row / hc, yy = row - c * hc;
+              s_crop[row * wc + xx] = img[((long long)c * H + (ymin + yy)) * W + xmin + xx];
+            }
       }
     }
     // square-source pixel (c, sy, sx) -> crop pixel or the zero padding
