@@ -18,6 +18,7 @@ def main():
     Lq = int(os.environ.get("LQ", str(L)))
     pol = VIMAPolicy(embed_dim=256, xf_n_layers=1, sattn_n_heads=8, xattn_n_heads=8, precision="bf16", device="cuda:0")
     pol._ensure_handle()
+    pol.set_option("attn_qg", int(os.environ.get("QG", "1")))   # 2: 64 queries per wave
     q = torch.randn(B, Lq, H, D, device="cuda") * 0.4
     k = torch.randn(B, L, H, D, device="cuda") * 0.4
     v = torch.randn(B, L, H, D, device="cuda")
@@ -47,6 +48,11 @@ def main():
         tot = d.sum(1).mean()
         print("  wave-0 shader clocks per key tile (%d workgroups, %d tiles each): " % (d.shape[0], nt) +
               ", ".join(f"{n} {d[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; total {tot / nt:.0f}")
+    if os.environ.get("CHECK"):   # against the exact generic kernel
+        ref = torch.empty_like(out)
+        _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 0, p(ref), pol._stream()))
+        torch.cuda.synchronize()
+        print("  max |mfma - generic| =", (out - ref).abs().max().item(), "of", ref.abs().max().item())
     pr = pol.prof_read()["attention"]
     ms = pr["ms"] / max(pr["launches"], 1)
     print(f"attn mode{mode} B{B} H{H} Lq{Lq} Lk{L} D{D}: {ms:.3f} ms = {4.0 * B * H * Lq * L * D / ms / 1e9:.1f} TFLOP/s")

@@ -18,6 +18,7 @@ struct Tuning {
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
   int attn4_min_lq = -1;   // Lq from which the 4-wave LDS-shared flash kernel is used (default 64)
+  int attn_qg = -1;        // query groups of 32 per wave in that kernel: 1 (default) or 2 (64 queries per wave, Lq >= 256)
   long long* attn_dbg = nullptr;   // device buffer [workgroups*8] of phase clocks of the 4-wave kernel (nullptr = off)
 };
 

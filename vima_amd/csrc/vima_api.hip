@@ -1208,6 +1208,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
 
   else if (k == "gemm_dbg_ptr") h->tune.gemm_dbg = reinterpret_cast<long long*>((uintptr_t)value);
   else if (k == "attn4_min_lq") h->tune.attn4_min_lq = (int)value;
+  else if (k == "attn_qg") h->tune.attn_qg = (int)value;
   else if (k == "attn_dbg_ptr") h->tune.attn_dbg = reinterpret_cast<long long*>((uintptr_t)value);
   else if (k == "attn_split") h->tune.attn_split = (int)value;
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
