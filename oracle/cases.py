@@ -38,6 +38,50 @@ SMALL_CASES = ("cfg1_T1", "cfg1_T2", "ragged_4M", "e384_long")
 BENCH_CASES = ("bench_200M", "bench_200M_o1", "cfg2_20M", "lp1024_200M")
 
 
+# ---- baseline policies: whole-frame RGB encoders, decoder-only GPT / Perceiver + XAttnGPT ----------
+_RAGGED = [[0, 0, 1, 0], [1, 0, 0, 0, 0, 1, 0], [0, 1]]
+BASELINE_CASES = {
+    "baseline_gpt": dict(kind="gpt", E=256, layers=2, heads=8, batch=3, layout=_RAGGED, steps=3, wseed=3, iseed=2235),
+    "baseline_gato": dict(kind="gato", E=256, layers=2, heads=8, batch=3, layout=_RAGGED, steps=2, wseed=4, iseed=2236),
+    "baseline_flamingo": dict(kind="flamingo", E=256, layers=2, heads=8, xheads=8, batch=3, layout=_RAGGED, steps=3, wseed=5,
+                              iseed=2237),
+    # E == 768: no t5_prompt_encoder_post_layer; head dim 64 self-attention; T = 1 without action tokens
+    "baseline_gato_768": dict(kind="gato", E=768, layers=1, heads=12, batch=2, segments=2, words=3, steps=1, wseed=6, iseed=2238),
+}
+
+
+def build_baseline_case(name):
+    c = BASELINE_CASES[name]
+    cfg = syn.BaselineConfig(c["kind"], c["E"], c["layers"], c["heads"], xattn_n_heads=c.get("xheads", 0), vocab_size=16)
+    B = c["batch"]
+    if "layout" in c:
+        prompts = syn.make_rgb_prompt(B, layout=c["layout"], seed=c["iseed"])
+    else:
+        prompts = syn.make_rgb_prompt(B, n_segments=c["segments"], words_per_segment=c["words"], seed=c["iseed"])
+    obs = syn.make_rgb_obs(c["steps"], B, seed=c["iseed"] + 100)
+    actions = syn.make_actions(c["steps"] - 1, B, seed=c["iseed"] + 200) if c["steps"] > 1 else None
+    return cfg, prompts, obs, actions
+
+
+def baseline_state_dict(name, cfg=None):
+    cfg = cfg or build_baseline_case(name)[0]
+    return syn.make_baseline_state_dict(cfg, BASELINE_CASES[name]["wseed"], head_gain=0.5)
+
+
+def run_baseline(policy, prompts, obs, actions):
+    """Drive any object with the method surface of the reference's baseline policies (forward takes no obs mask)."""
+    import torch
+    with torch.no_grad():
+        ptok, pmask = policy.forward_prompt_assembly(prompts)
+        otok = policy.forward_obs_token(obs)
+        atok = None if actions is None else policy.forward_action_token(actions)
+        pred = policy.forward(otok, atok, ptok, pmask)
+    out = dict(prompt_tokens=ptok, prompt_masks=pmask, obs_tokens=otok, predicted=pred)
+    if atok is not None:
+        out["action_tokens"] = atok
+    return out
+
+
 def build_case(name):
     c = CASES[name]
     cfg = syn.config(c["model"], xattn_n_positions=c["npos"])

@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shim                       # noqa: E402
-from oracle.cases import CASES, build_case, run_policy, case_state_dict, gold_view, gold_keys  # noqa: E402
+from oracle.cases import (CASES, BASELINE_CASES, build_case, run_policy, case_state_dict, gold_view, gold_keys,  # noqa: E402
+                          build_baseline_case, baseline_state_dict, run_baseline)
+from oracle.baseline_oracle import build_baseline_oracle  # noqa: E402
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS  # noqa: E402
 from vima_amd import synthetic as syn            # noqa: E402
 
@@ -78,5 +80,42 @@ def main():
         del pol, orc, sd
 
 
+def main_baselines():
+    """tests/golden/baseline_*.npz: outputs of the reference's VIMAGPTPolicy / VIMAGatoPolicy / VIMAFlamingoPolicy."""
+    outdir = os.path.join(ROOT, "tests", "golden")
+    only = sys.argv[1:]
+    for name in BASELINE_CASES:
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        cfg, prompts, obs, actions = build_baseline_case(name)
+        sd = baseline_state_dict(name, cfg)
+        pol = ref_shim.build_reference_baseline(cfg.kind, **cfg.ctor_kwargs())
+        pol.load_state_dict(sd, strict=True)
+        out = run_baseline(pol, prompts, obs, actions)
+        with torch.no_grad():
+            out["raw_logits"] = torch.cat([torch.cat([m(out["predicted"][-1:]) for m in pol.action_decoder._decoders[k].mlps], dim=-1)
+                                           for k in ACTION_KEYS], dim=-1)
+            img = prompts[2]["rgb"]
+            out["obj_encoder"] = pol.obj_encoder(rgb=img)
+        orc = build_baseline_oracle(cfg, sd)
+        o_out = run_baseline(orc, prompts, obs, actions)
+        o_out["raw_logits"] = orc.action_logits(o_out["predicted"][-1:])
+        o_out["obj_encoder"] = orc.obj_encoder(img)
+        print(f"== {name}: cfg={cfg} ({time.time() - t0:.1f}s)")
+        for k in out:
+            a, b = out[k], o_out[k]
+            if a.dtype in (torch.bool, torch.int64):
+                print(f"   {k:20s} {tuple(a.shape)} exact={bool((a == b).all())}")
+            else:
+                print(f"   {k:20s} {tuple(a.shape)} max|ref|={a.abs().max().item():.4g} max|oracle-ref|={(a - b).abs().max().item():.3g}")
+        arrays = {k: v.detach().cpu().numpy() for k, v in out.items()}
+        arrays["_sd_checksum"] = np.float64(syn.state_dict_checksum(sd))
+        arrays["_torch_version"] = np.array(torch.__version__)
+        np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **arrays)
+        del pol, orc, sd
+
+
 if __name__ == "__main__":
     main()
+    main_baselines()

@@ -12,6 +12,7 @@ Why shims are needed (each verified in this container):
   * transformers 5.x removed `get_device_map`, `assert_device_map`, `checkpoint`
     from modeling_t5 (only used in dead model-parallel code)  -> dummy attributes
   * `PreTrainedModel.get_head_mask` is gone              -> returns [None]*n
+  * `OpenAIGPTModel.get_head_mask` (gpt/gpt.py:173, baselines) likewise
   * HF `Attention.forward` (openai) changed signature; binding the reference's
     `_attn(..., head_mask, output_attentions)` positionally against 5.x would
     silently zero the attention                          -> 4.x parent body restored
@@ -178,6 +179,10 @@ def load_reference():
         return [a] + o[1:]
 
     C.Attention.forward = attn_fwd
+    # the decoder-only baselines (VIMAGPTPolicy / VIMAGatoPolicy) use a second copy of the same classes (gpt/gpt.py)
+    G = sys.modules["vima.nn.seq_modeling.gpt.gpt"]
+    G.Attention.forward = attn_fwd
+    G.OpenAIGPTModel.get_head_mask = lambda self, hm, n, *a, **k: [None] * n
     _loaded = vima
     return vima
 
@@ -207,4 +212,14 @@ def build_reference_policy(embed_dim, xf_n_layers, sattn_n_heads, xattn_n_heads,
             xattn_n_head=xattn_n_heads, xattn_ff_expanding=4,
             xattn_n_positions=xattn_n_positions, use_geglu=True)
     pol.eval()
+    return pol
+
+
+def build_reference_baseline(kind, **ctor):
+    """Construct one of the reference's baseline policies (vima/policy/vima_{gpt,gato,flamingo}_policy.py) in eval mode.
+    They read `self.device`, which plain nn.Module does not define (the reference's training harness does): set it."""
+    vima = load_reference()
+    cls = {"gpt": vima.policy.VIMAGPTPolicy, "gato": vima.policy.VIMAGatoPolicy, "flamingo": vima.policy.VIMAFlamingoPolicy}[kind]
+    pol = cls(**ctor).eval()
+    pol.device = torch.device("cpu")
     return pol

@@ -295,9 +295,10 @@ class OraclePolicy:
         f = f * _lin(a, sd[p + "gated_layer.weight"])                              # gate reads UN-normed a (:224)
         return _lin(f, sd[p + "linear2.weight"]) + a
 
-    def _block(self, i, x, key_mask_add):
-        """Block.forward (components.py:23-37), Attention._attn (:51-80), MLP.forward (:97-102)."""
-        sd, p = self.sd, f"xattn_gpt.h.{i}."
+    def _block(self, i, x, key_mask_add, prefix="xattn_gpt.h."):
+        """Block.forward (components.py:23-37), Attention._attn (:51-80), MLP.forward (:97-102); gpt/gpt.py:223-301 is a
+        second copy of the same classes (prefix "transformer.lm.h.", baseline policies)."""
+        sd, p = self.sd, f"{prefix}{i}."
         E, H = self.embed_dim, self.sattn_heads
         d = E // H
         B, L, _ = x.shape
@@ -307,7 +308,7 @@ class OraclePolicy:
         k = k.view(B, L, H, d).transpose(1, 2)
         v = v.view(B, L, H, d).transpose(1, 2)
         w = q @ k.transpose(-1, -2) / math.sqrt(d)
-        b = sd[p + "attn.bias"][:, :, :L, :L]
+        b = torch.tril(torch.ones(L, L, dtype=w.dtype, device=w.device)).view(1, 1, L, L)   # the `attn.bias` buffer
         w = w * b + -1e4 * (1 - b)                                                  # :63
         w = torch.softmax(w + key_mask_add, dim=-1)
         a = (w @ v).transpose(1, 2).reshape(B, L, E)

@@ -340,3 +340,199 @@ def to_device(x, device):
     if torch.is_tensor(x):
         return x.to(device)
     return x
+
+
+# --------------------------------------------------------------------------------------
+# baseline policies: VIMAGPTPolicy / VIMAGatoPolicy / VIMAFlamingoPolicy
+# --------------------------------------------------------------------------------------
+RGB_H, RGB_W, RGB_PATCH = 64, 128, 32      # img_size=(64, 128), vit_patch_size=32 (vima_gpt_policy.py:37-45)
+RGB_PATCHES = (RGB_H // RGB_PATCH) * (RGB_W // RGB_PATCH)
+PERCEIVER_LATENTS, PERCEIVER_BLOCKS, PERCEIVER_SELF_PER_BLOCK, PERCEIVER_HEADS = 4, 4, 4, 8   # vima_flamingo_policy.py:40-45
+
+
+@dataclass(frozen=True)
+class BaselineConfig:
+    """Constructor arguments of the reference's baseline policies. kind "gpt" / "gato": decoder-only HFGPT over
+    [prompt | sep | obs / action tokens] (vima_gpt_policy.py:12-20, vima_gato_policy.py:13-21); "flamingo": XAttnGPT over
+    Perceiver-resampled image tokens (vima_flamingo_policy.py:11-18; xattn_n_positions is hard-coded 256 there)."""
+    kind: str
+    embed_dim: int
+    n_layer: int
+    n_head: int
+    xattn_n_heads: int = 0
+    vocab_size: int = 40478
+    n_positions: int = 512
+    xattn_n_positions: int = 256
+
+    def ctor_kwargs(self):
+        if self.kind == "flamingo":
+            return dict(embed_dim=self.embed_dim, dt_n_layers=self.n_layer, dt_n_heads=self.n_head, xattn_n_heads=self.xattn_n_heads)
+        return dict(embed_dim=self.embed_dim, vocab_size=self.vocab_size, n_positions=self.n_positions, n_layer=self.n_layer,
+                    n_head=self.n_head)
+
+    @property
+    def obs_tokens(self):
+        """tokens one observation contributes to the sequence: 1 (gpt: cls features of both views concatenated),
+        2 * 8 patch tokens (gato), 4 latents (flamingo)"""
+        return {"gpt": 1, "gato": 2 * RGB_PATCHES, "flamingo": PERCEIVER_LATENTS}[self.kind]
+
+    @property
+    def obj_dim(self):
+        """obj_encoder.output_dim (obj_encoder.py:243-245: emb_dim * n_views for MultiViewRGBEncoder)"""
+        return 2 * self.embed_dim if self.kind == "gpt" else self.embed_dim
+
+    def asdict(self):
+        return asdict(self)
+
+
+def _gpt_block(I, h, E, n_positions, with_bias_buffer):
+    if with_bias_buffer:   # components.py registers the causal mask as a persistent buffer; gpt/gpt.py inherits HF's non-persistent one
+        I.const(h + "attn.bias", torch.tril(torch.ones(n_positions, n_positions)).view(1, 1, n_positions, n_positions))
+    w = I.normal(h + "attn.c_attn.weight", (E, 3 * E), 0.02)
+    w[:, : 2 * E] *= 3.0
+    I.normal(h + "attn.c_attn.bias", (3 * E,), 0.02)
+    I.normal(h + "attn.c_proj.weight", (E, E), 0.02)
+    I.normal(h + "attn.c_proj.bias", (E,), 0.02)
+    I.ln(h + "ln_1", E)
+    I.normal(h + "mlp.c_fc.weight", (E, 4 * E), 0.02)
+    I.normal(h + "mlp.c_fc.bias", (4 * E,), 0.02)
+    I.normal(h + "mlp.c_proj.weight", (4 * E, E), 0.02)
+    I.normal(h + "mlp.c_proj.bias", (E,), 0.02)
+    I.normal(h + "mlp.gated_layer.weight", (4 * E, E), 0.02)
+    I.ln(h + "ln_2", E)
+
+
+def make_baseline_state_dict(cfg: BaselineConfig, seed: int = 0, head_gain: float = 0.01) -> dict[str, torch.Tensor]:
+    """State dict with the key layout of the reference's baseline policies (probed from the reference modules in the
+    build container; tests/test_baseline_oracle.py loads it into them with strict=True)."""
+    E, N = cfg.embed_dim, cfg.n_layer
+    I = _Init(seed)
+    if cfg.kind == "flamingo":
+        p = "xattn_gpt."
+        I.const(p + "position_ids", torch.arange(cfg.n_positions))
+        I.const(p + "xattn_position_ids", torch.arange(cfg.xattn_n_positions))
+        I.normal(p + "positions_embed.weight", (cfg.n_positions, E), 0.02)
+        I.normal(p + "xattn_positions_embed.weight", (cfg.xattn_n_positions, E), 0.02)
+        for i in range(N):
+            _gpt_block(I, f"{p}h.{i}.", E, cfg.n_positions, True)
+        for i in range(N):
+            x = f"{p}xattns.{i}."
+            I.const(x + "kv_position_ids", torch.arange(cfg.xattn_n_positions))
+            I.ln(x + "layernorm", E)
+            I.normal(x + "query.weight", (E, E), 0.06)
+            kv = I.normal(x + "key_value.weight", (2 * E, E), 0.02)
+            kv[:E] *= 3.0
+            I.normal(x + "attention_out.weight", (E, E), 0.02)
+            I.ln(x + "ln", E)
+            I.normal(x + "linear1.weight", (4 * E, E), 0.02)
+            I.normal(x + "linear2.weight", (E, 4 * E), 0.02)
+            I.normal(x + "gated_layer.weight", (4 * E, E), 0.02)
+    else:
+        I.normal("prompt_sep_token", (E,), 0.5)
+        p = "transformer.lm."
+        I.const(p + "position_ids", torch.arange(cfg.n_positions))
+        I.normal(p + "tokens_embed.weight", (cfg.vocab_size, E), 0.02)     # never read (inputs_embeds path, gpt.py:69-73)
+        I.normal(p + "positions_embed.weight", (cfg.n_positions, E), 0.02)
+        for i in range(N):
+            _gpt_block(I, f"{p}h.{i}.", E, cfg.n_positions, False)
+    # ---- image encoder: (Gato)VisionTransformerRectangular (vit.py:83-135, :262-329) on 64x128 frames, 32x32 patches ----
+    v = "obj_encoder.cropped_img_encoder.vit."
+    W = VIT_WIDTH
+    sc = W ** -0.5
+    if cfg.kind == "gpt":
+        I.normal(v + "cls_token", (W,), sc)
+    I.normal(v + "pos_embed", (RGB_PATCHES + (1 if cfg.kind == "gpt" else 0), W), sc)
+    I.normal(v + "projection", (W, E), sc)
+    I.normal(v + "conv1.weight", (W, 3, RGB_PATCH, RGB_PATCH), 0.01)
+    I.ln(v + "ln_pre", W)
+    for j in range(VIT_LAYERS):
+        b = f"{v}blocks.{j}."
+        w = I.normal(b + "attn.in_proj_weight", (3 * W, W), 0.0255)
+        w[: 2 * W] *= 2.5
+        I.normal(b + "attn.in_proj_bias", (3 * W,), 0.02)
+        I.linear(b + "attn.out_proj", W, W, 0.0209)
+        I.ln(b + "ln_1", W)
+        I.linear(b + "mlp.c_fc", 4 * W, W, 0.0208)
+        I.linear(b + "mlp.c_proj", W, 4 * W, 0.0104)
+        I.ln(b + "ln_2", W)
+    I.ln(v + "ln_post", W)
+    if cfg.kind == "flamingo":   # HF PerceiverModel (modeling_perceiver.py:125-527), d_model = d_latents = E
+        pc = "obj_encoder.peceiver.model."     # (sic: the reference attribute is spelled `peceiver`, obj_encoder.py:177)
+        I.normal(pc + "embeddings.latents", (PERCEIVER_LATENTS, E), 1.0)
+
+        def layer(pre, cross):
+            a = pre + "attention."
+            I.ln(a + "self.layernorm1", E)
+            if cross:
+                I.ln(a + "self.layernorm2", E)
+            I.linear(a + "self.query", E, E, E ** -0.5 * 1.5)
+            I.linear(a + "self.key", E, E, E ** -0.5 * 1.5)
+            I.linear(a + "self.value", E, E, E ** -0.5)
+            I.linear(a + "output.dense", E, E, E ** -0.5 * 0.5)
+            I.ln(pre + "layernorm", E)
+            I.linear(pre + "mlp.dense1", E, E, E ** -0.5)     # widening factor 1 (PerceiverConfig defaults)
+            I.linear(pre + "mlp.dense2", E, E, E ** -0.5 * 0.5)
+        layer(pc + "encoder.cross_attention.", True)
+        for i in range(PERCEIVER_SELF_PER_BLOCK):
+            layer(f"{pc}encoder.self_attends.{i}.", False)
+    # ---- obs fusion / action encoder / action decoder: same modules as VIMAPolicy ----
+    I.normal("end_effector_encoder.weight", (2, 2), 0.7)
+    I.linear("obs_fusion_layer", E, cfg.obj_dim + 2, (cfg.obj_dim + 2) ** -0.5 * 0.58)
+    for k in ACTION_KEYS:
+        in_dim = 2 if k.endswith("position") else 4
+        I.mlp(f"action_encoder._embed_dict.{k}._layer", [in_dim, 256, 256])
+    if E != 1024:
+        I.linear("action_encoder._post_layer", E, 1024, 1024 ** -0.5 * 0.58)
+    for k in ACTION_KEYS:
+        for j, bins in enumerate(ACTION_DIMS[k]):
+            I.mlp(f"action_decoder._decoders.{k}.mlps.{j}", [E, 512, 512, bins], last_gain=head_gain)
+    # ---- word embedding + T5 encoder ----
+    I.normal("prompt_embedding._embed_layer.weight", (T5_VOCAB, 768), 1.0)
+    t5 = "t5_prompt_encoder.t5."
+    dead = torch.zeros(T5_VOCAB, 768)
+    I.const(t5 + "shared.weight", dead)
+    I.const(t5 + "encoder.embed_tokens.weight", dead)
+    d_model, inner = 768, T5_HEADS * T5_DKV
+    for l in range(T5_LAYERS):
+        a = f"{t5}encoder.block.{l}.layer.0."
+        I.normal(a + "SelfAttention.q.weight", (inner, d_model), (d_model * T5_DKV) ** -0.5 * 2.0)
+        I.normal(a + "SelfAttention.k.weight", (inner, d_model), d_model ** -0.5 * 1.5)
+        I.normal(a + "SelfAttention.v.weight", (inner, d_model), d_model ** -0.5)
+        I.normal(a + "SelfAttention.o.weight", (d_model, inner), inner ** -0.5)
+        if l == 0:
+            I.normal(a + "SelfAttention.relative_attention_bias.weight", (T5_BUCKETS, T5_HEADS), 1.0)
+        I.normal(a + "layer_norm.weight", (d_model,), 0.1, 1.0)
+        f = f"{t5}encoder.block.{l}.layer.1."
+        I.normal(f + "DenseReluDense.wi.weight", (T5_DFF, d_model), d_model ** -0.5)
+        I.normal(f + "DenseReluDense.wo.weight", (d_model, T5_DFF), T5_DFF ** -0.5)
+        I.normal(f + "layer_norm.weight", (d_model,), 0.1, 1.0)
+    I.normal(t5 + "encoder.final_layer_norm.weight", (d_model,), 0.1, 1.0)
+    if E != 768:
+        I.normal("t5_prompt_encoder_post_layer.weight", (E, 768), 768 ** -0.5)
+    I.mlp("prompt_obj_post_layer", [cfg.obj_dim, 768, 768, 768])
+    return I.sd
+
+
+def make_rgb_prompt(batch: int, layout: list[list[int]] | None = None, *, n_segments: int = 2, words_per_segment: int = 4,
+                    seed: int = 1234):
+    """`prompts` triple of the baseline policies (vima_gpt_policy.py:189-190): image_batch = {"rgb": {view: u8 [n_img,3,64,128]}}
+    (whole frames instead of object crops)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    if layout is None:
+        layout = [([0] * words_per_segment + [1]) * n_segments for _ in range(batch)]
+    assert len(layout) == batch
+    n_words = sum(t == 0 for p in layout for t in p)
+    n_img = sum(t == 1 for p in layout for t in p)
+    word_batch = torch.randint(0, 32100, (n_words,), generator=g)
+    rgb = {v: torch.randint(0, 256, (n_img, 3, RGB_H, RGB_W), generator=g, dtype=torch.int64).to(torch.uint8) for v in VIEWS}
+    return layout, word_batch, MapDict(rgb=MapDict(rgb))
+
+
+def make_rgb_obs(steps: int, batch: int, seed: int = 4321):
+    """obs dict of the baseline policies (vima_gpt_policy.py:249-259): {"rgb": {view: u8 [T,B,3,64,128]}, "ee": i64 [T,B]}"""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    rgb = {v: torch.randint(0, 256, (steps, batch, 3, RGB_H, RGB_W), generator=g, dtype=torch.int64).to(torch.uint8) for v in VIEWS}
+    ee = torch.randint(0, 2, (steps, batch), generator=g)
+    return MapDict(rgb=MapDict(rgb), ee=ee)
