@@ -30,6 +30,16 @@ typedef void* vima_stream_t; /* hipStream_t */
  * only carry 3 mantissa bits) -- measured and reported by the tests, not covered by the 1e-3 gate of the bf16 mode. */
 enum { VIMA_PRECISION_FP32 = 0, VIMA_PRECISION_BF16 = 1, VIMA_PRECISION_FP8W = 2 };
 
+/* Which policy class of vima/policy/ the handle implements. VIMA is the hot path (vima_policy.py); the other three are the
+ * reference's baseline policies, which consume whole 64x128 RGB frames instead of object crops:
+ *   GPT      VIMAGPTPolicy      (vima_gpt_policy.py): cls feature of a rectangular ViT per view, decoder-only HFGPT over
+ *                                [prompt | sep | obs, action, obs, ...]
+ *   GATO     VIMAGatoPolicy     (vima_gato_policy.py): the 2 x 8 patch tokens of every frame pair go into the same sequence
+ *   FLAMINGO VIMAFlamingoPolicy (vima_flamingo_policy.py): patch tokens resampled to 4 latents by a Perceiver, then XAttnGPT
+ * For them xf_n_layers / sattn_n_heads are the constructor's n_layer / n_head (dt_n_layers / dt_n_heads); xattn_n_heads is
+ * only used by FLAMINGO (pass n_head otherwise). */
+enum { VIMA_POLICY_VIMA = 0, VIMA_POLICY_GPT = 1, VIMA_POLICY_GATO = 2, VIMA_POLICY_FLAMINGO = 3 };
+
 /* Constructor arguments of VIMAPolicy (vima_policy.py:12-19) plus the two table sizes the reference hard-codes
  * (xattn_n_positions=256 at vima_policy.py:30, n_positions=512 at xattn_gpt.py:18). */
 typedef struct VimaConfig {
@@ -41,6 +51,7 @@ typedef struct VimaConfig {
   int32_t n_positions;
   int32_t precision; /* VIMA_PRECISION_*: operand type of the matrix-core GEMMs / attention (accumulation, residual
                         stream, LayerNorm and softmax statistics are always fp32) */
+  int32_t policy_kind; /* VIMA_POLICY_* (ABI version 3; 0 = VIMAPolicy) */
 } VimaConfig;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
@@ -124,6 +135,29 @@ int vima_action_head(VimaHandle* h, const float* tokens, int R, float* out_logit
  * indices i64, keys in sorted order: pose0_position [R,2], pose0_rotation [R,4], pose1_position [R,2],
  * pose1_rotation [R,4] -> out f32 [R,E]. */
 int vima_action_embed(VimaHandle* h, const int64_t* const idx[4], int R, float* out, vima_stream_t stream);
+
+/* ---- baseline policies (policy_kind != VIMA_POLICY_VIMA) ---------------------------------------- */
+/* Tokens one frame pair contributes: Q = 1 (GPT), 16 (GATO: 8 patches x 2 views), 4 (FLAMINGO: Perceiver latents); feature
+ * width of obj_encoder's output Eo = 2E (GPT: views concatenated on the feature axis, obj_encoder.py:232-245) or E. */
+int vima_rgb_tokens_per_image(const VimaConfig* cfg);
+/* obj_encoder.forward of the handle's policy (MultiViewRGBEncoder obj_encoder.py:207-246, GatoMultiViewRGBEncoder :98-145,
+ * MultiViewRGBPerceiverEncoder :148-204): rgb[v] u8 [n,3,64,128] -> out f32 [n, Q, Eo]. */
+int vima_rgb_encode(VimaHandle* h, const uint8_t* const rgb[2], int n, float* out, vima_stream_t stream);
+/* forward_obs_token (vima_gpt_policy.py:249-259, vima_gato_policy.py:253-264, vima_flamingo_policy.py:216-227): leading dims
+ * [T,B] flattened to n; ee i64 [n] in {0,1} -> out f32 [n, Q, E] (GPT: Q = 1, the reference returns [T,B,E]). */
+int vima_rgb_obs_encode(VimaHandle* h, const uint8_t* const rgb[2], const int64_t* ee, int n, float* out, vima_stream_t stream);
+/* forward_prompt_assembly (vima_gpt_policy.py:189-247, vima_gato_policy.py:190-251, vima_flamingo_policy.py:156-214): like
+ * vima_prompt_encode with whole frames: tok_src codes >= 0 word index, -1 padding, <= -2 image token -(code+2) = img*Q + q;
+ * every assembled token is valid (these policies have no object masks). -> out_tokens f32 [B,Lp,E], out_mask u8 [B,Lp]. */
+int vima_rgb_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, const uint8_t* const rgb[2], int n_img,
+                           const int32_t* tok_src, int B, int Lp, float* out_tokens, uint8_t* out_mask, vima_stream_t stream);
+/* VIMAGPTPolicy.forward / VIMAGatoPolicy.forward (vima_gpt_policy.py:118-187, vima_gato_policy.py:115-188) -> HFGPT.forward
+ * (gpt/gpt.py:45-80): sequence [prompt (Lp) | prompt_sep_token | o_1..o_Q, a, o_1..o_Q, a, ...] per sample, key mask = prompt
+ * mask then ones, position ids continuing after the sample's valid prompt tokens. obs_tok f32 [T,B,Q,E], act_tok f32
+ * [L_act,B,E] or NULL (L_act in {T-1, T}), prompt/strides/mask as in vima_decode -> out f32 [T,B,E].
+ * (VIMAFlamingoPolicy.forward is vima_decode with an all-ones obs_mask.) */
+int vima_seq_decode(VimaHandle* h, const float* obs_tok, const float* act_tok, int T, int B, int L_act, const float* prompt,
+                    int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp, float* out, vima_stream_t stream);
 
 /* ---- image preprocessing in front of the policy ------------------------------------------- */
 /* The per-object work of prepare_obs / prepare_prompt (/root/reference/scripts/example.py:374-473 and :243-371; numpy +

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/vima_hip.h but not exported by libvima_hip.so"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert lib.vima_abi_version() == 2
+    assert lib.vima_abi_version() == 3
 
 
 def test_t5_bucket_matches_oracle():
@@ -54,6 +54,22 @@ def test_required_params_match_reference_key_layout(name):
         assert not (set(req) & set(ign))
     assert sum(k.startswith("xattn_gpt.h.") for k in req) == 13 * n
     assert sum(k.startswith("xattn_gpt.xattns.") for k in req) == 10 * n
+
+
+@pytest.mark.parametrize("kind", ["gpt", "gato", "flamingo"])
+def test_baseline_required_params_match_reference_key_layout(kind):
+    """Baseline policies: required + ignorable keys == the keys of the reference modules' state dicts
+    (synthetic.make_baseline_state_dict loads into them with strict=True, tests/test_baseline_oracle.py)."""
+    from vima_amd.baselines import build_baseline
+    cfg = syn.BaselineConfig(kind, 256, 2, 8, xattn_n_heads=8 if kind == "flamingo" else 0, vocab_size=16)
+    pol = build_baseline(cfg)
+    req, ign = pol.expected_keys()
+    sd = syn.make_baseline_state_dict(cfg, 0)
+    assert len(req) == len(set(req)) and not (set(req) & set(ign))
+    assert set(req) | set(ign) == set(sd.keys()), (sorted(set(sd) - set(req) - set(ign))[:5], sorted((set(req) | set(ign)) - set(sd))[:5])
+    assert pol._obj_xf_num_queries == cfg.obs_tokens
+    with pytest.raises(RuntimeError):   # strict: a VIMAPolicy state dict does not fit
+        pol.load_state_dict(syn.make_state_dict(syn.config("2M"), 0), strict=True)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

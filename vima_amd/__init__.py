@@ -3,6 +3,7 @@
 Drop-in for the reference's public entry points on this path:
     vima.create_policy_from_ckpt  (vima/__init__.py:7-16)
     vima.policy.VIMAPolicy        (vima/policy/vima_policy.py:11-322)
+    vima.policy.VIMA{GPT,Gato,Flamingo}Policy (vima/policy/vima_*_policy.py; the baselines)
 The compute lives in hand-written HIP kernels behind a C ABI (include/vima_hip.h, vima_amd/csrc/);
 this package is the thin Python host side. Importing it does not require a GPU; constructing a policy does.
 """
@@ -10,13 +11,16 @@ from __future__ import annotations
 
 import os
 
-__all__ = ["VIMAPolicy", "create_policy_from_ckpt"]
+__all__ = ["VIMAPolicy", "VIMAGPTPolicy", "VIMAGatoPolicy", "VIMAFlamingoPolicy", "create_policy_from_ckpt"]
 
 
 def __getattr__(name):   # lazy: `import vima_amd.synthetic` must not need the built library
     if name == "VIMAPolicy":
         from .policy import VIMAPolicy
         return VIMAPolicy
+    if name in ("VIMAGPTPolicy", "VIMAGatoPolicy", "VIMAFlamingoPolicy"):   # vima/policy/__init__.py:2-4 (baselines)
+        from . import baselines
+        return getattr(baselines, name)
     raise AttributeError(name)
 
 

@@ -18,10 +18,11 @@ vp = ctypes.c_void_p
 
 class VimaConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("embed_dim", "xf_n_layers", "sattn_n_heads", "xattn_n_heads",
-                                     "xattn_n_positions", "n_positions", "precision")]
+                                     "xattn_n_positions", "n_positions", "precision", "policy_kind")]
 
 
 PRECISION = {"fp32": 0, "bf16": 1, "fp8w": 2}
+POLICY_KIND = {"vima": 0, "gpt": 1, "gato": 2, "flamingo": 3}   # VIMA_POLICY_* (include/vima_hip.h)
 
 # exported symbol -> (restype, argtypes); must list every function declared in include/vima_hip.h
 PROTOTYPES = {
@@ -41,6 +42,12 @@ PROTOTYPES = {
                                    vp, c_i64, c_i64, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "vima_decode_step": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, c_i64, c_i64, vp,
                                         ctypes.c_int, vp, vp]),
+    "vima_rgb_tokens_per_image": (ctypes.c_int, [ctypes.POINTER(VimaConfig)]),
+    "vima_rgb_encode": (ctypes.c_int, [vp, vp * 2, ctypes.c_int, vp, vp]),
+    "vima_rgb_obs_encode": (ctypes.c_int, [vp, vp * 2, vp, ctypes.c_int, vp, vp]),
+    "vima_rgb_prompt_encode": (ctypes.c_int, [vp, vp, ctypes.c_int, vp * 2, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    "vima_seq_decode": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, c_i64, c_i64, vp, ctypes.c_int,
+                                       vp, vp]),
     "vima_action_head": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
     "vima_action_embed": (ctypes.c_int, [vp, vp * 4, ctypes.c_int, vp, vp]),
     "vima_op_linear": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

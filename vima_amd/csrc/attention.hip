@@ -940,12 +940,17 @@ static int launch_generic_t(const AttnDev& d, const AttnArgs& a, hipStream_t st)
     case 32: hipLaunchKernelGGL((attn_generic_kernel<T, 32>), grid, dim3(64), sh, st, d); break;
     case 64: hipLaunchKernelGGL((attn_generic_kernel<T, 64>), grid, dim3(64), sh, st, d); break;
     case 128: hipLaunchKernelGGL((attn_generic_kernel<T, 128>), grid, dim3(64), sh, st, d); break;
+    // the Perceiver of VIMAFlamingoPolicy has 8 heads whatever the width: head dims 40 / 48 / 80 / 96 for E = 320 ... 768
+    case 40: hipLaunchKernelGGL((attn_generic_kernel<T, 40>), grid, dim3(64), sh, st, d); break;
+    case 48: hipLaunchKernelGGL((attn_generic_kernel<T, 48>), grid, dim3(64), sh, st, d); break;
+    case 80: hipLaunchKernelGGL((attn_generic_kernel<T, 80>), grid, dim3(64), sh, st, d); break;
+    case 96: hipLaunchKernelGGL((attn_generic_kernel<T, 96>), grid, dim3(64), sh, st, d); break;
     default: return (int)hipErrorInvalidValue;
   }
   return (int)hipGetLastError();
 }
 
-// head dims 16 / 32 / 64 / 128 (the MFMA flash kernels cover 32 and 64; the others run here)
+// head dims 16 / 32 / 40 / 48 / 64 / 80 / 96 / 128 (the MFMA flash kernels cover 32 and 64; the others run here)
 int launch_attn_generic(const AttnArgs& a, bool is_bf16, hipStream_t st) {
   if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0) return 0;
   if (a.mode == ATTN_T5 && !a.relbias) return (int)hipErrorInvalidValue;

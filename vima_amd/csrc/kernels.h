@@ -123,6 +123,20 @@ int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uin
 // out[t,b,:] = x[b, (Q-1) + (Q+1) t, :]
 int launch_gather_pred(const float* x, float* out, int T, int B, int Q, int Lq, int E, hipStream_t st);
 
+// ---- baseline policies (baseline_kernels.hip): whole RGB frames, decoder-only sequences
+// uint8 frames [M,3,H,W] -> normalised patch matrix T [M*(H/P)*(W/P), 3*P*P], k = c*P*P + py*P + px
+int launch_patchify_rect(const uint8_t* img, void* outT, int M, int H, int W, int P, bool is_bf16, hipStream_t st);
+// tokens = LN_pre(concat([cls,] patches) + pos): pre fp32 [M*n_patch,768] -> x fp32 [M*S,768] and / or xT; cls == nullptr: S = n_patch
+int launch_vit_embed_rect(const float* pre, const float* cls, const float* pos, const float* g, const float* b, float* x, void* xT,
+                          int M, int S, int n_patch, bool is_bf16, hipStream_t st);
+// out[r,:] = src[r % period,:] (fp32)
+int launch_broadcast_rows(const float* src, float* out, long long rows, int E, int period, hipStream_t st);
+// decoder-only input [B,L,E]: [prompt | sep | (Q obs tokens, action)*] + positions_embed, key mask [B,L]
+int launch_seq_embed(const float* prompt, long long sb, long long sl, const uint8_t* pmask, const float* sep, const float* obs_tok,
+                     const float* act_tok, const float* pos_table, int n_pos, float* x32, void* xT, uint8_t* mask, int B, int L, int Lp,
+                     int Q, int E, bool is_bf16, hipStream_t st);
+int launch_fill_u8(uint8_t* p, long long n, uint8_t v, hipStream_t st);
+
 // ---------------------------------------------------------------- attention
 // ViT: 5-token (S <= 8) multi-head attention on packed qkv T [M*S, 3*W] -> T [M*S, W]; head dim 32
 int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st);

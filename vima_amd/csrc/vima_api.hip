@@ -224,6 +224,13 @@ struct VimaHandle {
   Lin head1; void* head2_W = nullptr; float* head2_b = nullptr; Lin head3[kNumHeadsOut];
   struct { float *w0, *b0; } act0[4];
   void* act1_W = nullptr; float* act1_b = nullptr; Lin act_post;
+  // ---- baseline policies (policy_kind != VIMA; baselines.inc): the ViT above holds the rectangular variant (vit_S tokens per
+  // frame, 32x32 patches); decoder-only kinds use the Block half of `dec` + sep_token; FLAMINGO adds the Perceiver
+  int vit_S = 5, vit_patches = 4;
+  float* sep_token = nullptr;
+  struct PercLayer { float *ln1g, *ln1b, *ln2g, *ln2b, *lng, *lnb; Lin q, kv, o, d1, d2; };   // kv = [key; value] stacked
+  PercLayer perc_cross, perc_self[4];
+  float* latents = nullptr;
   // ---- profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -333,24 +340,35 @@ struct Packer {
 int pack_all(VimaHandle* h) {
   Packer P{h, ""};
   const int E = h->cfg.embed_dim, NL = h->cfg.xf_n_layers;
+  const int kind = h->cfg.policy_kind;
+  const bool is_vima = kind == VIMA_POLICY_VIMA;
+  const bool has_xattn = is_vima || kind == VIMA_POLICY_FLAMINGO;
+  // baselines: (Gato)VisionTransformerRectangular on 64x128 frames with 32x32 patches (vit.py:83-135, 262-329): 8 patch
+  // tokens, + cls for VIMAGPTPolicy; projection [768, E]
+  const bool vit_cls = is_vima || kind == VIMA_POLICY_GPT;
+  const int patch = is_vima ? 16 : 32;
+  h->vit_patches = is_vima ? 4 : 8;
+  h->vit_S = h->vit_patches + (vit_cls ? 1 : 0);
+  const int vit_out = is_vima ? kVitW : E;
+  const int obj_dim = kind == VIMA_POLICY_GPT ? 2 * E : E;   // obj_encoder.output_dim (obj_encoder.py:243-245)
   char buf[256];
   // ---- ViT (vit.py:137-169)
   const std::string v = "obj_encoder.cropped_img_encoder.vit.";
-  h->vit.cls = P.vec(v + "cls_token", kVitW);
-  if (const HostParam* p = P.get(v + "pos_embed", {5, kVitW})) h->vit.pos = P.up_f32(p->data.data(), p->data.size());
+  if (vit_cls) h->vit.cls = P.vec(v + "cls_token", kVitW);
+  if (const HostParam* p = P.get(v + "pos_embed", {h->vit_S, kVitW})) h->vit.pos = P.up_f32(p->data.data(), p->data.size());
   h->vit.lnpre_g = P.vec(v + "ln_pre.weight", kVitW);
   h->vit.lnpre_b = P.vec(v + "ln_pre.bias", kVitW);
   h->vit.lnpost_g = P.vec(v + "ln_post.weight", kVitW);
   h->vit.lnpost_b = P.vec(v + "ln_post.bias", kVitW);
-  if (const HostParam* p = P.get(v + "conv1.weight", {kVitW, 3, 16, 16})) {  // [768, 3*16*16] already [N,K]
-    h->vit.conv.N = kVitW; h->vit.conv.K = 768;
+  if (const HostParam* p = P.get(v + "conv1.weight", {kVitW, 3, patch, patch})) {  // [768, 3*P*P] already [N,K]
+    h->vit.conv.N = kVitW; h->vit.conv.K = 3 * patch * patch;
     P.pack_w(h->vit.conv, p->data);
   }
-  if (const HostParam* p = P.get(v + "projection", {kVitW, kVitW})) {        // x @ projection: [in,out] -> [out,in]
-    std::vector<float> t((size_t)kVitW * kVitW);
+  if (const HostParam* p = P.get(v + "projection", {kVitW, vit_out})) {        // x @ projection: [in,out] -> [out,in]
+    std::vector<float> t((size_t)kVitW * vit_out);
     for (int k = 0; k < kVitW; ++k)
-      for (int n = 0; n < kVitW; ++n) t[(size_t)n * kVitW + k] = p->data[(size_t)k * kVitW + n];
-    h->vit.projection.N = kVitW; h->vit.projection.K = kVitW;
+      for (int n = 0; n < vit_out; ++n) t[(size_t)n * kVitW + k] = p->data[(size_t)k * vit_out + n];
+    h->vit.projection.N = vit_out; h->vit.projection.K = kVitW;
     P.pack_w(h->vit.projection, t);
   }
   for (int j = 0; j < kVitLayers; ++j) {
@@ -367,7 +385,7 @@ int pack_all(VimaHandle* h) {
     B.proj = P.linear(b + "mlp.c_proj", kVitW, 4 * kVitW, true);
   }
   // ---- bbox MLPs + per-view projection (obj_encoder.py:44-64)
-  for (int vi = 0; vi < 2; ++vi) {
+  for (int vi = 0; vi < 2 && is_vima; ++vi) {
     const std::string bp = std::string("obj_encoder.bbox_mlp.") + kViews[vi];
     if (const HostParam* p = P.get(bp + ".0.weight", {768, 4})) h->view[vi].w0 = P.up_f32(p->data.data(), p->data.size());
     h->view[vi].b0 = P.vec(bp + ".0.bias", 768);
@@ -377,26 +395,27 @@ int pack_all(VimaHandle* h) {
   }
   // ---- obs fusion (vima_policy.py:47-49,253-256): Linear(E+2 -> E) on cat(img, ee_emb[ee]) = W[:, :E] img + table[ee]
   {
-    const HostParam* w = P.get("obs_fusion_layer.weight", {E, E + 2});
+    const int Kf = obj_dim;   // width of the image feature in front of the 2 end-effector columns
+    const HostParam* w = P.get("obs_fusion_layer.weight", {E, Kf + 2});
     const HostParam* b = P.get("obs_fusion_layer.bias", {E});
     const HostParam* ee = P.get("end_effector_encoder.weight", {2, 2});
     if (w && b && ee) {
-      std::vector<float> wm((size_t)E * E), tab((size_t)2 * E);
+      std::vector<float> wm((size_t)E * Kf), tab((size_t)2 * E);
       for (int n = 0; n < E; ++n) {
-        for (int k = 0; k < E; ++k) wm[(size_t)n * E + k] = w->data[(size_t)n * (E + 2) + k];
+        for (int k = 0; k < Kf; ++k) wm[(size_t)n * Kf + k] = w->data[(size_t)n * (Kf + 2) + k];
         for (int e = 0; e < 2; ++e) {
-          float t = ee->data[e * 2 + 0] * w->data[(size_t)n * (E + 2) + E];
-          t = fmaf(ee->data[e * 2 + 1], w->data[(size_t)n * (E + 2) + E + 1], t);
+          float t = ee->data[e * 2 + 0] * w->data[(size_t)n * (Kf + 2) + Kf];
+          t = fmaf(ee->data[e * 2 + 1], w->data[(size_t)n * (Kf + 2) + Kf + 1], t);
           tab[(size_t)e * E + n] = t + b->data[n];
         }
       }
-      h->fuse.N = E; h->fuse.K = E;
+      h->fuse.N = E; h->fuse.K = Kf;
       P.pack_w(h->fuse, wm);
       h->ee_table = P.up_f32(tab.data(), tab.size());
     }
   }
   // ---- prompt object post MLP (vima_policy.py:103-108)
-  h->pobj[0] = P.linear("prompt_obj_post_layer.0", 768, E, true);
+  h->pobj[0] = P.linear("prompt_obj_post_layer.0", 768, obj_dim, true);
   h->pobj[1] = P.linear("prompt_obj_post_layer.3", 768, 768, true);
   h->pobj[2] = P.linear("prompt_obj_post_layer.6", 768, 768, true);
   // ---- word embedding table (word_embd.py:8-23)
@@ -452,16 +471,21 @@ int pack_all(VimaHandle* h) {
   h->t5_final = P.vec(t5 + "final_layer_norm.weight", kT5Model);
   h->has_t5_post = (E != kT5Model);
   if (h->has_t5_post) h->t5_post = P.linear("t5_prompt_encoder_post_layer", E, kT5Model, false);
-  // ---- XAttnGPT (xattn_gpt.py:45-68, components.py)
-  if (const HostParam* p = P.get("xattn_gpt.positions_embed.weight", {h->cfg.n_positions, E}))
+  // ---- XAttnGPT (xattn_gpt.py:45-68, components.py); decoder-only baselines: HFGPT (gpt/gpt.py:83-100), whose Block is
+  // a second copy of the same class (gpt/gpt.py:223-301) under "transformer.lm."
+  const std::string gp = has_xattn ? "xattn_gpt." : "transformer.lm.";
+  if (const HostParam* p = P.get(gp + "positions_embed.weight", {h->cfg.n_positions, E}))
     h->pos_emb = P.up_f32(p->data.data(), p->data.size());
-  if (const HostParam* p = P.get("xattn_gpt.xattn_positions_embed.weight", {h->cfg.xattn_n_positions, E}))
-    h->xpos_emb = P.up_f32(p->data.data(), p->data.size());
+  if (has_xattn)
+    if (const HostParam* p = P.get("xattn_gpt.xattn_positions_embed.weight", {h->cfg.xattn_n_positions, E}))
+      h->xpos_emb = P.up_f32(p->data.data(), p->data.size());
+  if (!has_xattn) h->sep_token = P.vec("prompt_sep_token", E);
   h->dec.resize(NL);
   for (int i = 0; i < NL; ++i) {
     auto& D = h->dec[i];
     snprintf(buf, sizeof buf, "xattn_gpt.xattns.%d.", i);
     const std::string x = buf;
+    if (has_xattn) {
     D.xln_g = P.vec(x + "layernorm.weight", E); D.xln_b = P.vec(x + "layernorm.bias", E);
     D.xln2_g = P.vec(x + "ln.weight", E); D.xln2_b = P.vec(x + "ln.bias", E);
     D.q = P.linear(x + "query", E, E, false);
@@ -470,7 +494,8 @@ int pack_all(VimaHandle* h) {
     D.l1 = P.linear(x + "linear1", 4 * E, E, false);
     D.gate = P.linear(x + "gated_layer", 4 * E, E, false);
     D.l2 = P.linear(x + "linear2", E, 4 * E, false);
-    snprintf(buf, sizeof buf, "xattn_gpt.h.%d.", i);
+    }
+    snprintf(buf, sizeof buf, "%sh.%d.", gp.c_str(), i);
     const std::string b = buf;
     D.ln1_g = P.vec(b + "ln_1.weight", E); D.ln1_b = P.vec(b + "ln_1.bias", E);
     D.ln2_g = P.vec(b + "ln_2.weight", E); D.ln2_b = P.vec(b + "ln_2.bias", E);
@@ -534,6 +559,39 @@ int pack_all(VimaHandle* h) {
     if (ok) { h->act1_W = P.up_T(w); h->act1_b = P.up_f32(b.data(), b.size()); }
     // ActionEmbedding._post_layer is nn.Identity when embed_dim == 4 * 256 (action_embd.py:24-27): no such key then
     if (E != 1024) h->act_post = P.linear("action_encoder._post_layer", E, 1024, true);
+  }
+  if (kind == VIMA_POLICY_FLAMINGO) {
+    // HF PerceiverModel (modeling_perceiver.py:125-527; obj_encoder.py:176-204 `peceiver` sic): 4 latents, one cross-attention
+    // layer, 4 self-attention layers applied 4 times, widening factor 1
+    const std::string pc = "obj_encoder.peceiver.model.";
+    if (const HostParam* p = P.get(pc + "embeddings.latents", {4, E})) h->latents = P.up_f32(p->data.data(), p->data.size());
+    auto layer = [&](VimaHandle::PercLayer& L, const std::string& pre, bool cross) {
+      const std::string a = pre + "attention.";
+      L.ln1g = P.vec(a + "self.layernorm1.weight", E); L.ln1b = P.vec(a + "self.layernorm1.bias", E);
+      if (cross) { L.ln2g = P.vec(a + "self.layernorm2.weight", E); L.ln2b = P.vec(a + "self.layernorm2.bias", E); }
+      L.q = P.linear(a + "self.query", E, E, true);
+      const HostParam* kw = P.get(a + "self.key.weight", {E, E});
+      const HostParam* kb = P.get(a + "self.key.bias", {E});
+      const HostParam* vw = P.get(a + "self.value.weight", {E, E});
+      const HostParam* vb = P.get(a + "self.value.bias", {E});
+      if (kw && kb && vw && vb) {
+        std::vector<float> w(kw->data), b(kb->data);
+        w.insert(w.end(), vw->data.begin(), vw->data.end());
+        b.insert(b.end(), vb->data.begin(), vb->data.end());
+        L.kv.N = 2 * E; L.kv.K = E;
+        P.pack_w(L.kv, w);
+        L.kv.b = P.up_f32(b.data(), b.size());
+      }
+      L.o = P.linear(a + "output.dense", E, E, true);
+      L.lng = P.vec(pre + "layernorm.weight", E); L.lnb = P.vec(pre + "layernorm.bias", E);
+      L.d1 = P.linear(pre + "mlp.dense1", E, E, true);
+      L.d2 = P.linear(pre + "mlp.dense2", E, E, true);
+    };
+    layer(h->perc_cross, pc + "encoder.cross_attention.", true);
+    for (int i = 0; i < 4; ++i) {
+      snprintf(buf, sizeof buf, "%sencoder.self_attends.%d.", pc.c_str(), i);
+      layer(h->perc_self[i], buf, false);
+    }
   }
   if (!P.missing.empty()) return fail("vima_finalize_params (strict):" + P.missing);
   return 0;
@@ -985,6 +1043,13 @@ int check_ready(VimaHandle* h) {
   return 0;
 }
 
+int vima_only(VimaHandle* h, const char* fn) {
+  if (!h) return fail("null handle");
+  if (h->cfg.policy_kind != VIMA_POLICY_VIMA)
+    return fail(std::string(fn) + ": object-crop entry point of VIMAPolicy called on a baseline-policy handle (use the vima_rgb_* entry points)");
+  return 0;
+}
+
 
 // ---------------------------------------------------------------------------------------------- hipGraph replay
 void drop_graphs(VimaHandle* h) {
@@ -1066,12 +1131,14 @@ int run_graphed(VimaHandle* h, std::string key, hipStream_t user, F&& fn) {
   return rc;
 }
 
+#include "baselines.inc"
+
 }  // namespace
 
 // =================================================================================================== C ABI
 extern "C" {
 
-int vima_abi_version(void) { return 2; }   // 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w
+int vima_abi_version(void) { return 3; }   // 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w; 3: + VimaConfig.policy_kind, baseline-policy entry points
 const char* vima_last_error(void) { return g_err.c_str(); }
 int vima_t5_bucket(int rel) { return t5_bucket(rel); }
 void vima_fp8_e4m3_encode(const float* src, uint8_t* dst, int64_t n) {
@@ -1093,6 +1160,11 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16 && cfg->precision != VIMA_PRECISION_FP8W)
     return fail("vima_create: bad precision");
   if (cfg->n_positions <= 0 || cfg->n_positions > 512 || cfg->xattn_n_positions <= 0) return fail("vima_create: bad table sizes");
+  if (cfg->policy_kind < VIMA_POLICY_VIMA || cfg->policy_kind > VIMA_POLICY_FLAMINGO) return fail("vima_create: bad policy_kind");
+  if (cfg->policy_kind == VIMA_POLICY_FLAMINGO) {   // the Perceiver has 8 heads whatever the width (vima_flamingo_policy.py:42-44)
+    const int dp = E / 8;
+    if (E % 8 || !(head_ok(dp) || dp == 40 || dp == 48 || dp == 80 || dp == 96)) return fail("vima_create: embed_dim / 8 is not a supported Perceiver head dim");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail("vima_create: no HIP device available -- this library has no CPU fallback");
@@ -1267,6 +1339,7 @@ int vima_graph_stats(VimaHandle* h, int64_t* replays, int64_t* captures) {
 
 int vima_obj_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2], int n, int qv, float* out,
                     vima_stream_t stream) {
+  if (int e = vima_only(h, "vima_obj_encode")) return e;
   if (int e = check_ready(h)) return e;
   Run R{h, (hipStream_t)stream};
   void* featT = R.wsT((size_t)n * 2 * qv * h->cfg.embed_dim);
@@ -1277,7 +1350,7 @@ int vima_obj_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t*
 int vima_obs_encode(VimaHandle* h, const uint8_t* const crops[2], const int64_t* const bbox[2],
                     const uint8_t* const mask[2], const int64_t* ee, int n, int qv, float* out_tokens, uint8_t* out_mask,
                     vima_stream_t stream) {
-  if (!h) return fail("null handle");
+  if (int e = vima_only(h, "vima_obs_encode")) return e;
   const std::string key = gkey("obs_encode", {(long long)(uintptr_t)crops[0], (long long)(uintptr_t)crops[1], (long long)(uintptr_t)bbox[0],
                                               (long long)(uintptr_t)bbox[1], (long long)(uintptr_t)mask[0], (long long)(uintptr_t)mask[1],
                                               (long long)(uintptr_t)ee, n, qv, (long long)(uintptr_t)out_tokens, (long long)(uintptr_t)out_mask});
@@ -1311,6 +1384,7 @@ int vima_t5_encode(VimaHandle* h, const float* x, const uint8_t* mask, int B, in
 int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, const uint8_t* const crops[2],
                        const int64_t* const bbox[2], const uint8_t* const mask[2], int n_img, int qv,
                        const int32_t* tok_src, int B, int Lp, float* out_tokens, uint8_t* out_mask, vima_stream_t stream) {
+  if (int e = vima_only(h, "vima_prompt_encode")) return e;
   if (int e = check_ready(h)) return e;
   (void)n_words;
   Run R{h, (hipStream_t)stream};
@@ -1353,6 +1427,8 @@ static int decode_prepare(VimaHandle* h, const float* act_tok, int T, int B, int
                           DecodePlan& P) {
   if (!h) return fail("null handle");
   if (!h->finalized) return fail("weights not finalized: call vima_set_param for every key, then vima_finalize_params");
+  if (h->cfg.policy_kind != VIMA_POLICY_VIMA && h->cfg.policy_kind != VIMA_POLICY_FLAMINGO)
+    return fail("vima_decode: the handle's policy has no XAttnGPT (decoder-only baselines use vima_seq_decode)");
   HIPCK(hipSetDevice(h->device));
   const int E = h->cfg.embed_dim;
   const bool inc = step >= 0;
@@ -1565,6 +1641,95 @@ int vima_decode_step(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mas
   });
   if (!rc) decode_commit(h, P, B, Q, Lp, step);
   return rc;
+}
+
+// ---- baseline policies --------------------------------------------------------------------------
+int vima_rgb_tokens_per_image(const VimaConfig* cfg) {
+  if (!cfg || cfg->policy_kind == VIMA_POLICY_VIMA) return 0;
+  return rgb_tokens_per_image(cfg->policy_kind);
+}
+
+int vima_rgb_encode(VimaHandle* h, const uint8_t* const rgb[2], int n, float* out, vima_stream_t stream) {
+  if (int e = baseline_ready(h, "vima_rgb_encode")) return e;
+  Run R{h, (hipStream_t)stream};
+  return rgb_obj_encode(R, rgb, n, out, nullptr);
+}
+
+int vima_rgb_obs_encode(VimaHandle* h, const uint8_t* const rgb[2], const int64_t* ee, int n, float* out, vima_stream_t stream) {
+  if (int e = baseline_ready(h, "vima_rgb_obs_encode")) return e;
+  if (n <= 0) return 0;
+  Run R{h, (hipStream_t)stream};
+  const int E = h->cfg.embed_dim, Q = rgb_tokens_per_image(h->cfg.policy_kind);
+  const int Kf = h->fuse.K;            // 2E (GPT: one row per frame pair) or E (one row per token)
+  const int rows = n * Q;
+  void* featT = R.wsT((size_t)rows * Kf);
+  if (R.err) return R.err;
+  if (rgb_obj_encode(R, rgb, n, nullptr, featT)) return R.err;
+  // obs_fusion_layer on cat(img_feats, ee_feats) (vima_gpt_policy.py:256-258; the ee feature repeated over the Q tokens,
+  // vima_gato_policy.py:261-263): W[:, :Kf] . feats + (W[:, Kf:] . ee_emb[ee] + b)
+  R.linear(featT, Kf, h->fuse, rows, ACT_NONE, nullptr, 0, nullptr, 0, out, E, nullptr, 0);
+  OTHER(R, launch_add_row_table(out, rows, E, h->ee_table, (const long long*)ee, Q, R.st), "ee_table");
+  return R.err;
+}
+
+int vima_rgb_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, const uint8_t* const rgb[2], int n_img,
+                           const int32_t* tok_src, int B, int Lp, float* out_tokens, uint8_t* out_mask, vima_stream_t stream) {
+  if (int e = baseline_ready(h, "vima_rgb_prompt_encode")) return e;
+  (void)n_words;
+  Run R{h, (hipStream_t)stream};
+  const int E = h->cfg.embed_dim, Q = rgb_tokens_per_image(h->cfg.policy_kind);
+  const int Kf = h->fuse.K;
+  const int orows = n_img * Q;
+  float* objtok = R.ws<float>((size_t)(orows > 0 ? orows : 1) * 768);
+  uint8_t* objmask = R.ws<uint8_t>((size_t)(orows > 0 ? orows : 1));
+  if (R.err) return R.err;
+  if (orows > 0) {
+    void* featT = R.wsT((size_t)orows * Kf);
+    void* p1 = R.wsT((size_t)orows * 768);
+    void* p2 = R.wsT((size_t)orows * 768);
+    if (R.err) return R.err;
+    if (rgb_obj_encode(R, rgb, n_img, nullptr, featT)) return R.err;
+    // prompt_obj_post_layer (vima_gpt_policy.py:207)
+    R.linear(featT, Kf, h->pobj[0], orows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, p1, 768);
+    R.linear(p1, 768, h->pobj[1], orows, ACT_RELU, nullptr, 0, nullptr, 0, nullptr, 0, p2, 768);
+    R.linear(p2, 768, h->pobj[2], orows, ACT_NONE, nullptr, 0, nullptr, 0, objtok, 768, nullptr, 0);
+    OTHER(R, launch_fill_u8(objmask, orows, 1, R.st), "fill");   // no object masks in these policies: every image token is valid
+  }
+  const int rows = B * Lp;
+  float* x = R.ws<float>((size_t)rows * 768);
+  if (R.err) return R.err;
+  OTHER(R, launch_prompt_assemble(tok_src, (const long long*)word_ids, h->word_table, objtok, objmask, x, out_mask, rows, 768, R.st),
+        "prompt_assemble");
+  if (!h->has_t5_post) return t5_stack(R, x, out_mask, B, Lp, out_tokens, nullptr);
+  void* yT = R.wsT((size_t)rows * 768);
+  if (R.err) return R.err;
+  if (t5_stack(R, x, out_mask, B, Lp, nullptr, yT)) return R.err;
+  return R.linear(yT, 768, h->t5_post, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
+}
+
+int vima_seq_decode(VimaHandle* h, const float* obs_tok, const float* act_tok, int T, int B, int L_act, const float* prompt,
+                    int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask, int Lp, float* out, vima_stream_t stream) {
+  if (int e = baseline_ready(h, "vima_seq_decode")) return e;
+  if (h->cfg.policy_kind == VIMA_POLICY_FLAMINGO)
+    return fail("vima_seq_decode: VIMAFlamingoPolicy decodes with XAttnGPT (vima_decode with an all-ones obs_mask)");
+  const int E = h->cfg.embed_dim, Q = rgb_tokens_per_image(h->cfg.policy_kind);
+  if (T <= 0 || B <= 0 || Lp <= 0) return fail("vima_seq_decode: empty input");
+  if (L_act < 0 || L_act > T || (L_act > 0 && !act_tok) || L_act < T - 1) return fail("vima_seq_decode: L_act must be T-1 or T");
+  const int L = Lp + 1 + T * Q + L_act;
+  if (L > h->cfg.n_positions)   // positions_embed lookup beyond the table (gpt/gpt.py:177-185 raises IndexError)
+    return fail("vima_seq_decode: sequence of " + std::to_string(L) + " tokens exceeds n_positions " + std::to_string(h->cfg.n_positions), 34);
+  Run R{h, (hipStream_t)stream};
+  const int rq = B * L;
+  float* x32 = R.ws<float>((size_t)rq * E);
+  void* xT = R.wsT((size_t)rq * E);
+  uint8_t* mask = R.ws<uint8_t>((size_t)rq);
+  if (R.err) return R.err;
+  OTHER(R, launch_seq_embed(prompt, stride_b, stride_l, prompt_mask, h->sep_token, obs_tok, act_tok, h->pos_emb, h->cfg.n_positions, x32,
+                            xT, mask, B, L, Lp, Q, E, h->bf16, R.st), "seq_embed");
+  if (hfgpt_stack(R, x32, xT, mask, B, L)) return R.err;
+  // predicted = tokens_out[Lp + 1 + Q - 1 :: Q + 1] (vima_gato_policy.py:185-187)
+  OTHER(R, launch_gather_pred(x32 + (size_t)(Lp + 1) * E, out, T, B, Q, L, E, R.st), "gather_pred");
+  return R.err;
 }
 
 int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logits, vima_stream_t stream) {
