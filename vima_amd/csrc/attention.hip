@@ -523,6 +523,16 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   gload(0);
   lstore(0);
   __syncthreads();
+  // The query fragments were requested above with plain global loads. hipcc's wait-count pass carries "these loads may
+  // still be pending" into the key-tile loop (it cannot know they landed during the first iteration) and therefore put
+  // `s_waitcnt vmcnt(3..0)` in front of the first S^T MFMAs of EVERY iteration -- right behind the prefetch loads of the next
+  // tile issued at the top of the iteration, i.e. the prefetch was waited for immediately and its latency was exposed on
+  // every tile (T5 shape: 0.418 -> 0.390 ms with 32, 0.405 -> 0.371 ms with 64 queries per wave). Consuming the fragments
+  // here (empty asm with the registers as in/out operands) makes the compiler wait for them ONCE, before the loop.
+#pragma unroll
+  for (int g = 0; g < QG; ++g)
+#pragma unroll
+    for (int dd = 0; dd < KD; ++dd) asm volatile("" : "+v"(qf[g][dd]));
   // per-phase shader-clock stamps of wave 0 (scripts/attn_micro.py STAMPS=1): compiled in only with -DVIMA_ATTN_STAMPS=1,
   // a run-time switch would split the loop body into basic blocks and pin the instruction schedule at every mark
 #ifndef VIMA_ATTN_STAMPS
@@ -780,6 +790,10 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnDev p) {
   gload(0);
   lstore(0);
   __syncthreads();
+  // wait for the query fragments ONCE, here: otherwise the wait-count pass waits for them in front of the first MFMAs of every
+  // iteration, i.e. for the prefetch loads of the next tile issued just before (see attn_mfma4_kernel)
+#pragma unroll
+  for (int dd = 0; dd < KD; ++dd) asm volatile("" : "+v"(qf[dd]));
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) gload(t + 1);
