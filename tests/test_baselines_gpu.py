@@ -118,3 +118,29 @@ def test_baseline_entry_points_reject_the_wrong_policy_kind():
     mask = torch.ones(2, 500, dtype=torch.bool, device=DEV)
     with pytest.raises(IndexError):
         pol.forward(torch.zeros(1, 2, 16, 256, device=DEV), None, long_prompt, mask)
+
+
+def test_flamingo_incremental_decoding_matches_full_history():
+    """VIMAFlamingoPolicy decodes with XAttnGPT: `forward_step` (episode K/V caches in the native handle) reproduces the rows of
+    the full-history `forward` that the reference's loop computes by re-feeding everything (fp32-operand mode, 2e-5)."""
+    cfg = syn.BaselineConfig("flamingo", 256, 2, 8, xattn_n_heads=8)
+    sd = syn.make_baseline_state_dict(cfg, seed=51)
+    pol = build_baseline(cfg, precision="fp32", device=DEV)
+    pol.load_state_dict(sd, strict=True)
+    T, B = 3, 2
+    prompts = syn.to_device(syn.make_rgb_prompt(B, layout=[[0, 1, 0], [1, 0, 0, 1]], seed=52), DEV)
+    obs = syn.to_device(syn.make_rgb_obs(T, B, seed=53), DEV)
+    actions = syn.to_device(syn.make_actions(T - 1, B, seed=54), DEV)
+    with torch.no_grad():
+        ptok, pmask = pol.forward_prompt_assembly(prompts)
+        otok = pol.forward_obs_token(obs)
+        atok = pol.forward_action_token(actions)
+        full = pol.forward(otok, atok, ptok, pmask)
+        for t in range(T):
+            step = pol.forward_step(otok[t], None if t == 0 else atok[t - 1], ptok, pmask, t)
+            assert max_abs(step, full[t]) < 2e-5 * max(1.0, full.abs().max().item()), (t, max_abs(step, full[t]))
+    gato = build_baseline(syn.BaselineConfig("gato", 256, 1, 8, vocab_size=8), device=DEV)
+    with pytest.raises(NotImplementedError):
+        gato.forward_step(None, None, None, None, 0)
+    with pytest.raises(ValueError):
+        build_baseline(syn.BaselineConfig("gato", 256, 1, 8, vocab_size=8), precision="fp8w", device=DEV)

@@ -57,6 +57,7 @@ def _worker(rank, world, port, global_batch, q):
             q.put((full, gathered))
         else:
             q.put((None, gathered))
+        dist.barrier()   # both ranks are done with their collectives before either tears the group down
     finally:
         dist.destroy_process_group()
 
@@ -77,5 +78,5 @@ def test_gloo_world2_allgather_equals_full_batch(global_batch):
     for _, g in res:
         assert g.shape == (global_batch, 700)
         # per-sample independence: sharded == full batch (fp32 CPU matmuls may differ in blocking -> tight tolerance)
-        assert torch.allclose(g, full, atol=2e-6, rtol=0)
+        assert torch.allclose(g, full, atol=5e-6, rtol=0), (g - full).abs().max().item()
     assert torch.equal(res[0][1], res[1][1]), "all ranks must hold identical gathered logits"

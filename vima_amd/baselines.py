@@ -25,6 +25,8 @@ class _BaselinePolicy(VIMAPolicy):
 
     def __init__(self, *, embed_dim, n_layer, n_head, xattn_n_heads=None, vocab_size=40478, n_positions=512,
                  precision="bf16", device=None):
+        if precision == "fp8w":
+            raise ValueError("precision 'fp8w' is validated for VIMAPolicy only; the baseline policies run in 'bf16' or 'fp32'")
         super().__init__(embed_dim=embed_dim, xf_n_layers=n_layer, sattn_n_heads=n_head,
                          xattn_n_heads=xattn_n_heads or n_head, xattn_n_positions=256, n_positions=n_positions,
                          precision=precision, device=device)
@@ -141,8 +143,15 @@ class _BaselinePolicy(VIMAPolicy):
             prompt_token.stride(0), _ptr(prompt_token_mask), Lp, _ptr(out), self._stream()))
         return out
 
-    def forward_step(self, *a, **k):
-        raise NotImplementedError("incremental decoding is implemented for VIMAPolicy only")
+    def forward_step(self, obs_token, prev_action_token, prompt_token, prompt_token_mask, step: int):
+        """Incremental decoding of one env step (see VIMAPolicy.forward_step). VIMAFlamingoPolicy decodes with XAttnGPT, so the
+        episode caches of `vima_decode_step` apply unchanged (every token valid); the decoder-only policies re-feed the history."""
+        if self.KIND != "flamingo":
+            raise NotImplementedError("incremental decoding needs the XAttnGPT episode caches: VIMAPolicy / VIMAFlamingoPolicy only")
+        if obs_token.dim() == 4:
+            obs_token = obs_token[-1]
+        ones = torch.ones(obs_token.shape[:2], dtype=torch.bool, device=self._device)
+        return VIMAPolicy.forward_step(self, obs_token, ones, prev_action_token, prompt_token, prompt_token_mask, step)
 
 
 class VIMAGPTPolicy(_BaselinePolicy):
