@@ -577,3 +577,31 @@ def test_full_size_200m_headline_batch_against_reference(golden_dir):
     otok_f, omask_f = pol32.forward_obs_token(syn.to_device(o_sub, DEV))
     logits_f = pol32.action_logits(pol32.forward(otok_f, omask_f, None, ptok_f, pmask_f)[-1])
     assert max_abs(logits_f, ref_logits) < 2e-5, max_abs(logits_f, ref_logits)
+
+
+def test_headline_batch_every_row_against_live_oracle():
+    """All 256 samples of the benchmarked batch (VIMA-200M, Lp=512, Q=8, bench.py's seeds), bf16 path, against the oracle run
+    live on the host in chunks of 32 (about a minute of CPU): every one of the 256 x 700 raw logits within the north_star
+    gate (1e-3 abs on logits of ~0.08), and the argmax of the 12 categorical heads reported over the whole batch."""
+    cfg = syn.config("200M", xattn_n_positions=512)
+    sd = syn.make_state_dict(cfg, 0)
+    B = 256
+    prompts = syn.make_prompt(B, n_segments=32, words_per_segment=8, q_per_view=4, seed=1236)
+    obs = syn.make_obs(1, B, 4, seed=1336)
+    pol = loaded_policy(cfg, sd, "bf16")
+    got = native_outputs(pol, prompts, obs, None)["raw_logits"].cpu().reshape(B, 700)
+    del pol
+    torch.cuda.empty_cache()
+    orc = OraclePolicy(sd, **cfg.ctor_kwargs())
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    ref = []
+    for lo in range(0, B, 32):
+        idx = list(range(lo, lo + 32))
+        ref.append(orc.cold_step(syn.cut_prompt(prompts, idx), syn.cut_obs(obs, idx)))
+    ref = torch.cat(ref, dim=0)
+    err = max_abs(got, ref)
+    agree, total, gap = _flip_report(got, ref)
+    print(f"[parity] headline batch, ALL 256 rows vs live oracle: max|logit err| {err:.3e} (max|logit| {ref.abs().max():.3g}), "
+          f"argmax agreement {agree}/{total} = {agree / total:.4f}, worst reference gap at a flip {gap:.3e}")
+    assert err < 1e-3, err
+    assert gap <= 2 * err + 1e-7
