@@ -19,6 +19,7 @@ def main():
     pol = VIMAPolicy(embed_dim=256, xf_n_layers=1, sattn_n_heads=8, xattn_n_heads=8, precision="bf16", device="cuda:0")
     pol._ensure_handle()
     pol.set_option("gemm_tile", tile)
+    pol.set_option("gemm_wide", int(os.environ.get("WIDE", "0")))       # 1: 256x384 persistent tile
     pol.set_option("gemm_raster", int(os.environ.get("RASTER", "0")))
     pol.set_option("gemm_epi", int(os.environ.get("EPI", "1")))
     pol.set_option("op_bf16_out", int(os.environ.get("BF16OUT", "0")))   # 1: bf16-only output like most in-model GEMMs

@@ -320,3 +320,41 @@ def test_attention(prec, impl, mode, B, H, Lq, Lk, D):
     assert torch.isfinite(out).all()
     # bf16: probabilities and outputs are rounded to bf16 (2^-9 relative each)
     assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,act,stream", [(16384, 768, 768, 0, 1), (16384, 768, 768, 0, 0), (16384, 2304, 128, 0, 0), (16384, 3072, 768, 3, 0),
+                                              (24576, 1536, 3072, 1, 0), (32768, 768, 3072, 0, 1)])
+def test_linear_wide_tile_is_bit_identical(M, N, K, act, stream):
+    """The 256x384 persistent tile (option gemm_wide; N a multiple of 384, bf16-only output or bf16 residual stream) accumulates
+    K in the same order as every other tile shape: identical bits to the 256x256 kernels, and the usual agreement with torch."""
+    pol = bare_policy("bf16")
+    pol.set_option("op_bf16_out", 1)
+    pol.set_option("op_stream_T", stream)
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * K ** -0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g) * 3.0 if stream else None
+        d = [None if t is None else t.cuda() for t in (A, W, b, None, r)]
+        outs = []
+        for wide in (0, 1):
+            pol.set_option("gemm_wide", wide)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, act,
+                                               ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.isfinite(outs[1]).all()
+        assert torch.equal(outs[0], outs[1])
+        ref = bf(A) @ bf(W).T + b
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 3:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        ref = bf(ref + bf(r)) if stream else bf(ref)
+        assert max_rel(outs[1], ref) < 6e-3, max_rel(outs[1], ref)
+    finally:
+        pol.set_option("gemm_wide", 0)
+        pol.set_option("op_bf16_out", 0)
+        pol.set_option("op_stream_T", 0)

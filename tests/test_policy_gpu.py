@@ -146,7 +146,7 @@ def test_bf16_argmax_agreement_o1_logits_live_oracle():
 
 
 
-@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 1}, {"graphs": 1},
+@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 1}, {"gemm_wide": 1}, {"graphs": 1},
                                   {"dual_stream": 0}, {"attn_split": 0}, {"gemm_epi": 0}, {"vit_prune_last": 0}])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_every_option_matches_reference_golden(opts, prec, golden_dir):

@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvima_hip.so")
+# VIMA_HIP_LIB: experiment builds only (scripts/build_ablate.sh A/B runs); the product library is the in-tree one
+LIB_PATH = os.environ.get("VIMA_HIP_LIB") or os.path.join(_HERE, "lib", "libvima_hip.so")
 
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 vp = ctypes.c_void_p

@@ -981,6 +981,283 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 256 x 384 persistent GEMM
+// The 256x256 loop period is the time the L2 -> LDS fabric needs for one K-slice, not the matrix pipe's: skipping a quarter
+// of the LDS-DMA pieces (timing-only experiment) shortens it by 18 %, half of them by 23 % (then the MFMA
+// floor). A 256 x 384 tile moves 80 KiB per 12.6 MFLOP instead of 64 KiB per 8.4 (154 instead of 128 FLOP per operand
+// byte). Same stream structure as gemm_persistent_kernel -- one workgroup per CU, the K-slices of all its tiles one
+// LDS-DMA stream, two stages -- with what the larger tile forces:
+//   * 8 waves of 128 x 96 (MI = 4, NI = 3): 192 accumulator registers per wave, 64 left -> fragments are SINGLE-buffered and
+//     reloaded as they retire (A fragment mi right after its last MFMA of the k-step, the W fragments between the MFMAs of
+//     the last mi); DMA source offsets are one register per operand plus scalar strides;
+//   * two 80-KiB stages fill the LDS: the epilogue slabs overlay the stage the tile's last slice was read from, so the
+//     slice that would be requested into it during that last slice (slice 1 of the next tile) is requested right after the
+//     epilogue instead (slice 0 of the next tile is in flight during the epilogue as before);
+//   * the epilogue walks the slabs column-group-major (ni outer) so that only one group of column constants is live.
+// EPI 1 (bf16 output, bias / activation / fused-RMSNorm row scale) and EPI 4 (bf16 residual stream, RMS partials).
+using TileW = Tile<256, 384, 2, 4, 128, 2>;
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const GemmDev p) {
+  using T = bf16_t;
+  using TL = TileW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = TL::RB, CPR = TL::CPR, BK = RB / 2, KSTEPS = BK / 16;
+  constexpr int MI = TL::MI, NI = TL::NI, NW = TL::NW, NP = TL::PA + TL::PW;
+  static_assert(TL::NS == 2 && RB == 128 && MI == 4 && NI == 3 && NW == 8 && NP <= MI * NI && EPI != 2 && EPI != 3, "written for TileW");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int G = gridDim.x;
+  const int nk = p.K / BK;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const char* W = reinterpret_cast<const char*>(p.W);
+  auto tile_at = [&](int v, int& tm, int& tn) {
+    const int idx = v >> 3;
+    const int q = idx / p.ntiles;
+    tn = idx - q * p.ntiles;
+    tm = q * 8 + (v & 7);
+  };
+  auto next_valid = [&](int v) {
+    while (v < p.vtotal) {
+      int tm, tn;
+      tile_at(v, tm, tn);
+      if (tm < p.mtiles) return v;
+      v += G;
+    }
+    return -1;
+  };
+  // LDS-DMA sources: piece i of an operand = 64 tile rows further down -> one per-lane byte offset per operand + a scalar stride
+  unsigned offA0, offW0;
+  const unsigned stepA = 64u * (unsigned)(p.lda * 2), stepW = 64u * (unsigned)(p.ldw * 2);
+  int iv, ikt = 0;
+  const int r0 = (w * 64 + lane) / CPR;
+  const int c0 = ((lane % CPR) ^ swz<RB>(r0)) * 16;
+  auto set_ptrs = [&](int v) {
+    int tm, tn;
+    tile_at(v, tm, tn);
+    offA0 = (unsigned)(tm * TL::BM + r0) * (unsigned)(p.lda * 2) + c0;
+    offW0 = (unsigned)(tn * TL::BN + r0) * (unsigned)(p.ldw * 2) + c0;
+  };
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue_piece = [&](int stage, int j) {
+    const int i = j < TL::PA ? j : j - TL::PA;
+    const int off = stage * TL::STAGE_BYTES + (j < TL::PA ? 0 : TL::A_BYTES) + (i * NW + w) * 1024;
+    if (j < TL::PA) glds16_asm_s(A, offA0 + (unsigned)i * stepA + (unsigned)(ikt * RB), smem_base + off);
+    else glds16_asm_s(W, offW0 + (unsigned)i * stepW + (unsigned)(ikt * RB), smem_base + off);
+  };
+  auto advance_issue = [&]() {
+    if (++ikt == nk) {
+      ikt = 0;
+      iv = next_valid(iv + G);
+      if (iv >= 0) set_ptrs(iv);
+    }
+  };
+  int cv = next_valid(blockIdx.x);
+  if (cv < 0) return;
+  iv = cv;
+  set_ptrs(iv);
+  for (int t = 0; t < 2; ++t) {   // nk >= 2 (launcher): both slices belong to the first tile
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue_piece(t, j);
+    advance_issue();
+  }
+  const int wm = w / TL::WN, wn = w % TL::WN;
+  const int arow = wm * (MI * 32) + l31;
+  const int wrow = wn * (NI * 32) + l31;
+  const int act = ACT >= 0 ? ACT : p.act;
+  int cur = 0;
+  bool pending = true;            // a slice younger than slice 0 of the coming tile is in flight (wave-uniform)
+
+  while (true) {
+    int tm, tn;
+    tile_at(cv, tm, tn);
+    const int m0 = tm * TL::BM, n0 = tn * TL::BN;
+    auto stamp = [&](int slot) {
+      if (p.dbg && tid == 0) {
+        long long* d = p.dbg + (long long)cv * 8;
+        d[slot] = (long long)__builtin_readcyclecounter();
+        if (slot == 0) d[4] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (slot == 3) d[5] = (long long)__builtin_amdgcn_s_memrealtime();
+      }
+    };
+    stamp(0);
+    // slice 0 of this tile has landed (its pieces are older than everything except the NP pieces of the slice after it)
+    if (pending) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float rscv[MI];
+    int tl31 = l31;
+    asm volatile("" : "+v"(tl31));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      rscv[mi] = 1.0f;
+      if (EPI == 1 && p.rs_ssq) {
+        const int mr = m0 + wm * (MI * 32) + mi * 32 + tl31;
+        rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
+      }
+    }
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    Frag<T> fa[MI], fw[NI];
+    {
+      const char* sA = smem + cur * TL::STAGE_BYTES;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi].template load<RB>(sA, arow + mi * 32, 0, hi);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fw[ni].template load<RB>(sA + TL::A_BYTES, wrow + ni * 32, 0, hi);
+    }
+    stamp(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nxt = cur ^ 1;
+      const char* sA = smem + cur * TL::STAGE_BYTES;
+      const char* nA = smem + nxt * TL::STAGE_BYTES;
+      const bool last_slice = kt + 1 == nk;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const bool last = kk + 1 == KSTEPS;
+        if (last) {
+          // slice kt+1 of the stream (or slice 0 of the next tile) has landed; every wave is done READING stage `cur` (the
+          // fragments of this last k-step were fetched during the previous one)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        const char* fA = last ? nA : sA;                    // where the NEXT k-step's fragments live
+        const int fk = last ? 0 : kk + 1;
+        const bool reload = !(last && last_slice);          // after the tile's last k-step the next fragments come at the next tile
+        const bool more = last && !last_slice && iv >= 0;   // request the slice two ahead into the stage just freed
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = mma(fw[ni], fa[mi], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && mi * NI + ni < NP) issue_piece(cur, mi * NI + ni);
+            if (mi == MI - 1 && reload) fw[ni].template load<RB>(fA + TL::A_BYTES, wrow + ni * 32, fk, hi);   // retired by this MFMA
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (reload) fa[mi].template load<RB>(fA, arow + mi * 32, fk, hi);   // its three MFMAs of this k-step are issued
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) advance_issue();
+      }
+      cur = nxt;
+    }
+    stamp(2);
+    // ---------------------------------------------------------------- epilogue: slabs overlay the stage of the last slice
+    auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
+    float* stg = reinterpret_cast<float*>(smem + (cur ^ 1) * TL::STAGE_BYTES + w * 4096);
+    T* outT = reinterpret_cast<T*>(p.outT);
+    float* ssq_out = EPI == 4 ? p.ssq_out : nullptr;
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int el31 = elane & 31, ehi = elane >> 5;
+    const int fw_ = fsw(el31);
+    constexpr int CPL = 8, LPR = 4, RPI = 16, NIT = 2;
+    const int ccol = (elane % LPR) * CPL;
+    const int crow = elane / LPR;
+    const int ncol0 = n0 + wn * (NI * 32) + ccol;
+    const int mrow0 = m0 + wm * (MI * 32) + crow;
+    constexpr bool AUX = EPI == 4;
+    const char* auxp = nullptr;
+    long long aux_ld = 0;
+    if (EPI == 4) { auxp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.resT) + (long long)mrow0 * p.ldresT + ncol0); aux_ld = (long long)p.ldresT * 2; }
+    f32x4_t aux[2][NIT];
+    auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {   // slab sl = ni * MI + mi (column-group-major)
+      const int ni = sl / MI, mi = sl % MI;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * 2;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
+      }
+    };
+    if (AUX) issue_aux(0, aux[0]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float4 bcol[2];
+      bcol[0] = bcol[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) {
+        bcol[0] = load4(p.bias + ncol0 + ni * 32);
+        bcol[1] = load4(p.bias + ncol0 + ni * 32 + 4);
+        if (!AUX) asm volatile("" : "+v"(bcol[0].x), "+v"(bcol[0].y), "+v"(bcol[0].z), "+v"(bcol[0].w), "+v"(bcol[1].x), "+v"(bcol[1].y), "+v"(bcol[1].z), "+v"(bcol[1].w));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        constexpr int NSLAB = MI * NI;
+        const int sl = ni * MI + mi;
+        const float rsc = rscv[mi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
+          *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
+        }
+        if (AUX) {
+          if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
+          f32x4_t(&a)[NIT] = aux[sl & 1];
+          // the bias loads of this column group (mi == 0) sit between the prefetch and this wait: they are older than the
+          // prefetch of the NEXT slab, so the same counts cover them
+          if (sl == 0 || sl + 1 == NSLAB) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(NIT));
+          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(2 * NIT));
+        }
+        const int n = ncol0 + ni * 32;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int r = it * RPI + crow;
+          const int f = fsw(r);
+          const long long m = mrow0 + mi * 32 + it * RPI;
+          float4 v[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
+            if (p.bias) { v[j].x += bcol[j].x; v[j].y += bcol[j].y; v[j].z += bcol[j].z; v[j].w += bcol[j].w; }
+            if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
+          }
+          if constexpr (EPI == 4) {
+            const f32x4_t g = aux[sl & 1][it];
+            const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
+            v[0].x += __uint_as_float(g0 << 16); v[0].y += __uint_as_float(g0 & 0xffff0000u);
+            v[0].z += __uint_as_float(g1 << 16); v[0].w += __uint_as_float(g1 & 0xffff0000u);
+            v[1].x += __uint_as_float(g2 << 16); v[1].y += __uint_as_float(g2 & 0xffff0000u);
+            v[1].z += __uint_as_float(g3 << 16); v[1].w += __uint_as_float(g3 & 0xffff0000u);
+          }
+          uint4 o;
+          o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
+          *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+          if (EPI == 4 && ssq_out) {
+            float sq = sumsq8_bf16(o);
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
+            if ((elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;
+          }
+        }
+      }
+    }
+    stamp(3);
+    // every wave is done with its slab before the deferred slice (slice 1 of the next tile) is requested into that stage
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pending = iv >= 0;
+    if (pending) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) issue_piece(cur ^ 1, j);
+      advance_issue();
+    }
+    cv = next_valid(cv + G);
+    if (cv < 0) break;
+  }
+}
+
 // Knob resolution: the handle's Tuning value when set (>= 0), otherwise the process default from the environment
 // (read once; never written afterwards, so it is safe to share between handles).
 inline int env_int(const char* name, int dflt) {
@@ -1001,6 +1278,8 @@ VIMA_KNOB(gemm_epi, gemm_epi, "VIMA_GEMM_EPI", g_env_epi, 1)
 VIMA_KNOB(gemm_persist, gemm_persist, "VIMA_GEMM_PERSIST", g_env_persist, 1)
 VIMA_KNOB(gemm_small, gemm_small, "VIMA_GEMM_SMALL", g_env_small, 1)
 VIMA_KNOB(gemm_splitk, gemm_splitk, "VIMA_GEMM_SPLITK", g_env_splitk, 0)
+int g_env_wide = -1;
+VIMA_KNOB(gemm_wide, gemm_wide, "VIMA_GEMM_WIDE", g_env_wide, 0)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1105,6 +1384,50 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
     case ACT_GELU * 8 + 2: return launch_persistent_inst<ACT_GELU, 2>(d, grid, st);
     case ACT_QUICKGELU * 8 + 1: return launch_persistent_inst<ACT_QUICKGELU, 1>(d, grid, st);
     default: return -1;   // no specialised instantiation (the all-runtime form spills): one-tile-per-workgroup kernel
+  }
+}
+
+template <int ACT, int EPI>
+int launch_wide_inst(const GemmDev& d, int grid, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<ACT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TileW::SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_wide_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(TileW::THREADS), TileW::SMEM_BYTES, st, d);
+  return (int)hipGetLastError();
+}
+
+// 256 x 384 persistent kernel (option gemm_wide): returns -1 when the problem does not fit it (caller falls back)
+int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (a.w8 || a.rb != 0 || a.batch > 1 || a.M % TileW::BM || a.N % TileW::BN || a.K < 2 * 64 || a.K % 64 || !d.wide8) return -1;
+  if ((long long)a.M * a.lda * 2 >= (1LL << 32) || (long long)a.N * a.ldw * 2 >= (1LL << 32)) return -1;
+  if (a.mul || a.res || a.out32) return -1;
+  int epi = 0;
+  if (!a.resT && !a.ssq_out) epi = 1;
+  else if (a.resT && !a.rs_ssq && a.act == ACT_NONE) epi = 4;
+  if (!epi) return -1;
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cu = n / 8 * 8;
+  }
+  d.mtiles = d.M / TileW::BM;
+  d.ntiles = d.N / TileW::BN;
+  if ((long long)d.mtiles * d.ntiles < 128) return -1;
+  d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
+  d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
+  const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
+  switch (a.act * 8 + epi) {
+    case ACT_NONE * 8 + 1: return launch_wide_inst<ACT_NONE, 1>(d, grid, st);
+    case ACT_RELU * 8 + 1: return launch_wide_inst<ACT_RELU, 1>(d, grid, st);
+    case ACT_QUICKGELU * 8 + 1: return launch_wide_inst<ACT_QUICKGELU, 1>(d, grid, st);
+    case ACT_NONE * 8 + 4: return launch_wide_inst<ACT_NONE, 4>(d, grid, st);
+    default: return -1;
   }
 }
 
@@ -1229,6 +1552,10 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (gemm_tile(a.tune) == 1) large = false;
     if (gemm_tile(a.tune) >= 2 && gemm_tile(a.tune) < 7) large = v;
     if (gemm_tile(a.tune) >= 7) large = false;
+    if (large && gemm_wide(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {
+      const int e = launch_wide(d, a, st);
+      if (e >= 0) return e;
+    }
     if (large && (gemm_tile(a.tune) == 0 || gemm_tile(a.tune) == 2) && gemm_persist(a.tune) && a.batch <= 1 &&
         a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
