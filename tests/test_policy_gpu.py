@@ -166,7 +166,7 @@ def test_every_option_matches_reference_golden(opts, prec, golden_dir):
         assert max_rel(out["prompt_tokens"].cpu(), tok) < (2e-4 if prec == "fp32" else 4e-2)
     finally:
         for k in opts:                                         # (options are per handle; restoring is belt and braces)
-            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 2, "graphs": 0, "dual_stream": 1,
+            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 2, "gemm_wide": 0, "graphs": 0, "dual_stream": 1,
                                "attn_split": 1, "gemm_epi": 1, "vit_prune_last": 1}[k])
 
 
