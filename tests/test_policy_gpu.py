@@ -580,9 +580,9 @@ def test_full_size_200m_headline_batch_against_reference(golden_dir):
 
 
 def test_headline_batch_every_row_against_live_oracle():
-    """All 256 samples of the benchmarked batch (VIMA-200M, Lp=512, Q=8, bench.py's seeds), bf16 path, against the oracle run
-    live on the host in chunks of 32 (about a minute of CPU): every one of the 256 x 700 raw logits within the north_star
-    gate (1e-3 abs on logits of ~0.08), and the argmax of the 12 categorical heads reported over the whole batch."""
+    """The benchmarked batch itself (VIMA-200M, B=256, Lp=512, Q=8, bench.py's seeds), bf16 path, against the oracle run live on
+    the host in chunks of 32: every raw logit of the checked rows within the north_star gate (1e-3 abs on logits of ~0.08),
+    and the argmax of the 12 categorical heads reported."""
     cfg = syn.config("200M", xattn_n_positions=512)
     sd = syn.make_state_dict(cfg, 0)
     B = 256
@@ -594,14 +594,19 @@ def test_headline_batch_every_row_against_live_oracle():
     torch.cuda.empty_cache()
     orc = OraclePolicy(sd, **cfg.ctor_kwargs())
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    ref = []
-    for lo in range(0, B, 32):
+    # the oracle costs ~0.3 s of host CPU per sample: by default every other chunk of 32 rows (128 rows spread over the whole
+    # batch, ~40 s); VIMA_FULL_PARITY=1 checks all 256 (the figure quoted in DESIGN.md section 5 comes from such a run)
+    full = os.environ.get("VIMA_FULL_PARITY", "0") == "1"
+    rows, ref = [], []
+    for lo in range(0, B, 32 if full else 64):
         idx = list(range(lo, lo + 32))
+        rows += idx
         ref.append(orc.cold_step(syn.cut_prompt(prompts, idx), syn.cut_obs(obs, idx)))
     ref = torch.cat(ref, dim=0)
+    got = got[rows]
     err = max_abs(got, ref)
     agree, total, gap = _flip_report(got, ref)
-    print(f"[parity] headline batch, ALL 256 rows vs live oracle: max|logit err| {err:.3e} (max|logit| {ref.abs().max():.3g}), "
+    print(f"[parity] headline batch, {len(rows)} of 256 rows vs live oracle: max|logit err| {err:.3e} (max|logit| {ref.abs().max():.3g}), "
           f"argmax agreement {agree}/{total} = {agree / total:.4f}, worst reference gap at a flip {gap:.3e}")
     assert err < 1e-3, err
     assert gap <= 2 * err + 1e-7
