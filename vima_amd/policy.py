@@ -145,7 +145,7 @@ class VIMAPolicy(nn.Module):
             missing_ign = [k for k in ign if k not in given]
             if missing or unexpected or missing_ign:
                 raise RuntimeError(
-                    "Error(s) in loading state_dict for VIMAPolicy:\n"
+                    f"Error(s) in loading state_dict for {type(self).__name__}:\n"
                     f"\tMissing key(s) in state_dict: {missing + missing_ign}.\n"
                     f"\tUnexpected key(s) in state_dict: {unexpected}.")
         elif missing:
