@@ -125,3 +125,22 @@ def test_fp8_e4m3_encoder_matches_torch():
     back = out.view(torch.float8_e4m3fn).float()
     rel = ((back - x).abs() / x.abs().clamp_min(2 ** -6)).max().item()
     assert rel <= 2 ** -4 + 1e-6                                                    # 3 mantissa bits: half an ulp = 1/16
+
+
+def test_baseline_policies_mirror_constructor_contract_on_cpu():
+    """Host-side contract of the baseline mirrors that needs no GPU: reference constructor arguments, exported names, fp8w
+    rejected, and (without a GPU) loud failure instead of a CPU fallback."""
+    import vima_amd
+    from vima_amd.baselines import VIMAGPTPolicy, VIMAGatoPolicy, VIMAFlamingoPolicy
+    assert vima_amd.VIMAGatoPolicy is VIMAGatoPolicy and vima_amd.VIMAFlamingoPolicy is VIMAFlamingoPolicy
+    g = VIMAGPTPolicy(embed_dim=256, vocab_size=16, n_positions=512, n_layer=2, n_head=8, dropout=0.1)
+    assert g._obj_xf_num_queries == 1 and g._cfg.policy_kind == _lib.POLICY_KIND["gpt"]
+    f = VIMAFlamingoPolicy(embed_dim=256, dt_n_layers=2, dt_n_heads=8, xattn_n_heads=8)
+    assert f._obj_xf_num_queries == 4 and f._cfg.xattn_n_positions == 256
+    with pytest.raises(ValueError):
+        VIMAGatoPolicy(embed_dim=256, n_layer=1, n_head=8, precision="fp8w")
+    with pytest.raises(ValueError):
+        VIMAGatoPolicy(embed_dim=250, n_layer=1, n_head=8)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            g.load_state_dict(syn.make_baseline_state_dict(syn.BaselineConfig("gpt", 256, 2, 8, vocab_size=16), 0), strict=True)
