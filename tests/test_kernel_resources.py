@@ -13,13 +13,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+_compiled = {}
+
+
+def _compile(src):
+    """One device-only compile per source: assembly on stdout, the resource-usage remarks on stderr (both tests of gemm.hip
+    share it)."""
+    if src not in _compiled:
+        out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
+                              "--cuda-device-only", "-S", os.path.join(ROOT, "vima_amd", "csrc", src), "-o", "-",
+                              "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        _compiled[src] = (out.stdout, out.stderr)
+    return _compiled[src]
+
+
 def _usage(src):
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
-                          "--cuda-device-only", "-c", os.path.join(ROOT, "vima_amd", "csrc", src), "-o", os.devnull,
-                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
+    _, remarks = _compile(src)
     res, name = {}, None
-    for line in out.stderr.splitlines():
+    for line in remarks.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
@@ -53,11 +65,7 @@ def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
     them before the data lands (guide: cdna_hip_programming.md 5.7 item 1). This audits the generated ISA: between an asm
     `global_load_dwordx4` and the counted `s_waitcnt` that covers it, no other instruction may name those registers. Loads
     are issued one slab ahead, so at every wait the batch issued right before it stays in flight and all older ones retire."""
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
-                          "--cuda-device-only", "-S", os.path.join(ROOT, "vima_amd", "csrc", "gemm.hip"), "-o", "-"],
-                         capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    src = out.stdout
+    src, _ = _compile("gemm.hip")
 
     def regs(tok):
         m = re.match(r"v\[(\d+):(\d+)\]", tok)
