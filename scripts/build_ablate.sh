@@ -19,6 +19,6 @@ for x in ${@:-1 2 4 8 3 5 7 15}; do
 done
 wait
 for x in ${@:-1 2 4 8 3 5 7 15}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_ablate/libvima_hip_abl$x.so $S/gemm_abl$x.o $C/obj/elementwise.o $C/obj/attention.o $C/obj/vima_api.o $C/obj/comm.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_ablate/libvima_hip_abl$x.so $S/gemm_abl$x.o $C/obj/elementwise.o $C/obj/attention.o $C/obj/vima_api.o $C/obj/comm.o $C/obj/preprocess.o $C/obj/baseline_kernels.o -ldl
 done
 ls -la $R/build_ablate

@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+L=scripts/micro/gemm_lab
+export STAMPS=1
+V=persist,pp0,pp
+timeout 120 $L 8192 8192 8192 1 0 5 $V | grep -v "host fp64"
+timeout 120 $L 131072 2304 768 1 0 5 $V | grep -v "host fp64"
+timeout 120 $L 131072 3072 768 1 1 5 $V
+timeout 120 $L 131072 768 768 4 0 5 $V
+timeout 120 $L 131072 768 3072 4 0 5 $V
+timeout 120 $L 8192 8192 8192 1 0 5 $V | grep -v "host fp64"

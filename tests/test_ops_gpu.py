@@ -322,6 +322,57 @@ def test_attention(prec, impl, mode, B, H, Lq, Lk, D):
     assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)
 
 
+
+@pytest.mark.parametrize("M,N,K,act,mode", [(16384, 768, 768, 0, "stream"), (16384, 768, 768, 0, "res32"), (16384, 2304, 128, 0, "bf16"),
+                                             (16384, 3072, 768, 3, "bf16"), (24576, 1536, 3072, 1, "bf16"), (32768, 768, 3072, 0, "stream"),
+                                             (12288, 1024, 256, 2, "gate"), (65536, 256, 1152, 0, "bf16")])
+def test_linear_pingpong_is_bit_identical(M, N, K, act, mode):
+    """The ping-pong (8-phase) main loop of the persistent 256x256 GEMM (option gemm_pp, default on) accumulates K in the
+    same order as the round-2 loop and shares its epilogue: identical bits for every specialised epilogue (bf16-only
+    output, GEGLU gate, fp32 residual, bf16 residual stream), several tiles per workgroup, short and long K, and the usual
+    agreement with torch."""
+    pol = bare_policy("bf16")
+    pol.set_option("op_bf16_out", 0 if mode == "res32" else 1)
+    pol.set_option("op_stream_T", 1 if mode == "stream" else 0)
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * K ** -0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g) * 3.0 if mode in ("stream", "res32") else None
+        mul = torch.randn(M, N, generator=g) if mode == "gate" else None
+        d = [None if t is None else t.cuda() for t in (A, W, b, mul, r)]
+        outs = []
+        for pp in (0, 1):
+            pol.set_option("gemm_pp", pp)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, act,
+                                               ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.isfinite(outs[1]).all()
+        assert torch.equal(outs[0], outs[1])
+        ref = bf(A) @ bf(W).T + b
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 2:
+            ref = torch.nn.functional.gelu(ref)
+        elif act == 3:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        if mode == "gate":
+            ref = bf(ref * bf(mul))
+        elif mode == "stream":
+            ref = bf(ref + bf(r))
+        elif mode == "res32":
+            ref = ref + r
+        else:
+            ref = bf(ref)
+        assert max_rel(outs[1], ref) < 6e-3, max_rel(outs[1], ref)
+    finally:
+        pol.set_option("gemm_pp", 1)
+        pol.set_option("op_bf16_out", 0)
+        pol.set_option("op_stream_T", 0)
+
 @pytest.mark.parametrize("M,N,K,act,stream", [(16384, 768, 768, 0, 1), (16384, 768, 768, 0, 0), (16384, 2304, 128, 0, 0), (16384, 3072, 768, 3, 0),
                                               (24576, 1536, 3072, 1, 0), (32768, 768, 3072, 0, 1)])
 def test_linear_wide_tile_is_bit_identical(M, N, K, act, stream):

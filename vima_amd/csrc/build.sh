@@ -9,7 +9,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-
 pids=()
 for f in gemm elementwise attention vima_api comm preprocess baseline_kernels; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kernels.h" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/vima_hip.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kernels.h" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/vima_hip.h" -nt "$obj" ] \
+     || { [ "$f" = vima_api ] && [ "$HERE/baselines.inc" -nt "$obj" ]; }; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

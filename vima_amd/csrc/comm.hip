@@ -43,7 +43,8 @@ void bind_rccl() {
   for (const char* n : paths)
     if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   if (!g_rccl.lib) {
-    g_rccl.err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?");
+    const char* e = dlerror();   // ONE call: dlerror() clears the pending error, a second call returns NULL
+    g_rccl.err = std::string("cannot load RCCL: ") + (e ? e : "?");
     return;
   }
 #define BIND(field, sym)                                                         \
@@ -95,6 +96,8 @@ int vima_comm_create(const uint8_t id[VIMA_COMM_ID_BYTES], int world, int rank, 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return cfail("vima_comm_create: no HIP device available");
   if (device < 0 || device >= ndev) return cfail("vima_comm_create: device index out of range");
   if (need_rccl()) return 1;
+  int prev_dev = -1;                                   // the caller's current device is restored on every exit path
+  (void)hipGetDevice(&prev_dev);
   if (hipSetDevice(device) != hipSuccess) return cfail("vima_comm_create: hipSetDevice failed");
   UniqueId u;
   memcpy(u.internal, id, kIdBytes);
@@ -103,6 +106,7 @@ int vima_comm_create(const uint8_t id[VIMA_COMM_ID_BYTES], int world, int rank, 
   c->rank = rank;
   c->device = device;
   int r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+  if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
   if (r != 0) {
     delete c;
     return cfail(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));

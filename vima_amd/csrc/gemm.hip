@@ -37,6 +37,11 @@ namespace {
 
 // The main-loop ablation builds behind DESIGN.md 4.2 (timing only, wrong results) are NOT part of this source:
 // scripts/ablate/gemm_ablate.patch re-creates them on a scratch copy (scripts/build_ablate.sh).
+#ifdef VIMA_GEMM_LAB
+constexpr bool kLab = true;    // scripts/micro/gemm_lab.hip: only the 256x256 bf16 kernels are instantiated (compile time)
+#else
+constexpr bool kLab = false;
+#endif
 constexpr bool kDephase = true;          // waves sharing a SIMD prefetch fragments at different points of a step
 constexpr bool kInterleaveDma = true;    // DMA pieces issued between the MFMAs of the last k-step
 
@@ -602,6 +607,170 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 256x256 tile epilogue
+// Shared by the persistent kernels (gemm_persistent_kernel, gemm_pp_kernel): the wave's 128x64 accumulator block goes
+// through a wave-private 4 KiB LDS slab (32x32 fp32, XOR-swizzled) and is finished row-contiguously.
+template <int ACT, int EPI, bool W8>
+__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
+                                                  int lane, int m0, int n0, int wm, int wn) {
+  using T = bf16_t;
+  constexpr int MI = 4, NI = 2;
+  const int act = ACT >= 0 ? ACT : p.act;
+  // ---------------------------------------------------------------- epilogue (32x32 fp32 slabs, private LDS region)
+  // acc[mi][ni][4q+e] = C[m0 + wm*128 + mi*32 + l31][n0 + wn*64 + ni*32 + 8q + 4hi + e]
+  // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
+  auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
+  float* stg = reinterpret_cast<float*>(slab);
+  constexpr bool WIDE8 = EPI == 1 || EPI == 2 || EPI == 4;      // bf16-only output, 16-byte stores
+  const T* mul = EPI == 2 ? reinterpret_cast<const T*>(p.mul) : nullptr;
+  const float* res = EPI == 3 ? p.res : nullptr;
+  float* out32 = EPI == 3 ? p.out32 : nullptr;
+  T* outT = reinterpret_cast<T*>(p.outT);
+  float* ssq_out = (EPI == 3 || EPI == 4) ? p.ssq_out : nullptr;
+  // the epilogue's per-lane address arithmetic is tile-invariant: hipcc would hoist it out of the tile loop and keep
+  // (spill) it across the main loop. An opaque copy of the lane id pins it here.
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+  const int el31 = elane & 31, ehi = elane >> 5;
+  const int fw_ = fsw(el31);
+  // Two phases per 32x32 slab: (1) the accumulators (x fused-RMSNorm row scale) go to the wave's LDS slab in MFMA
+  // layout; (2) they are read back ROW-CONTIGUOUSLY -- a lane owns 8 (bf16-only output) or 4 consecutive columns of a
+  // row, the SAME columns for every row and every mi -- and finished there: x weight scale (fp8w), + bias, activation,
+  // x gate, + residual, stores. Everything that depends on the column only (bias, fp8 scales) is therefore loaded once
+  // per tile. The per-row operands (gate / residual) are prefetched ONE SLAB AHEAD with inline-asm loads and counted
+  // `vmcnt` waits: left to hipcc, every row group waited `vmcnt(0)`, i.e. for the previous group's STORES as well (32
+  // serialised store round trips per tile, ~25 us of a 50 us tile at K = 768). VMEM operations of a wave retire in issue
+  // order; the launcher only sends M % 256 == 0, N % 256 == 0 here, so there are no bounds checks.
+  constexpr int CPL = WIDE8 ? 8 : 4;                            // columns per lane in the read-back layout
+  constexpr int LPR = 32 / CPL;                                 // lanes per slab row
+  constexpr int RPI = 64 / LPR;                                 // rows per wave-instruction (16 / 8)
+  constexpr int NIT = 32 / RPI;                                 // row groups per slab (2 / 4)
+  const int ccol = (elane % LPR) * CPL;                         // first column of this lane inside a slab
+  const int crow = elane / LPR;                                 // row of this lane inside a row group
+  const int ncol0 = n0 + wn * (NI * 32) + ccol;                 // + ni * 32
+  const int mrow0 = m0 + wm * (MI * 32) + crow;                 // + mi * 32 + it * RPI
+  float4 bcol[NI][CPL / 4], scol[NI][CPL / 4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < CPL / 4; ++j) {
+      bcol[ni][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      scol[ni][j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (p.bias) bcol[ni][j] = load4(p.bias + ncol0 + ni * 32 + 4 * j);
+      if (W8) scol[ni][j] = load4(p.wscale + ncol0 + ni * 32 + 4 * j);
+    }
+  // the column constants are needed (waited for) HERE, before the per-row prefetch starts: hipcc would otherwise wait for
+  // them at their first use with `vmcnt(0)`, i.e. for the prefetched loads issued in between as well
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < CPL / 4; ++j) {
+      if (p.bias) asm volatile("" : "+v"(bcol[ni][j].x), "+v"(bcol[ni][j].y), "+v"(bcol[ni][j].z), "+v"(bcol[ni][j].w));
+      if (W8) asm volatile("" : "+v"(scol[ni][j].x), "+v"(scol[ni][j].y), "+v"(scol[ni][j].z), "+v"(scol[ni][j].w));
+    }
+  // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
+  constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4;
+  const char* auxp = nullptr;
+  long long aux_ld = 0;                                         // bytes per row
+  if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
+  if (EPI == 3) { auxp = reinterpret_cast<const char*>(res + (long long)mrow0 * p.ldres + ncol0); aux_ld = (long long)p.ldres * 4; }
+  if (EPI == 4) { auxp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.resT) + (long long)mrow0 * p.ldresT + ncol0); aux_ld = (long long)p.ldresT * 2; }
+  f32x4_t aux[2][NIT];
+  auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {
+    const int mi = sl / NI, ni = sl % NI;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 3 ? 4 : 2);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
+    }
+  };
+  if (AUX) issue_aux(0, aux[0]);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const float rsc = rscv[mi];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      constexpr int NSLAB = MI * NI;
+      const int sl = mi * NI + ni;
+      // ---- (1) stage
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
+        *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
+      }
+      // ---- prefetch the next slab's per-row operand, then wait for this slab's (issued one slab ago). Younger VMEM
+      // operations at that point: the stores of the previous slab (EPI 2: exactly NIT; EPI 3: at least NIT) and the NIT
+      // loads just issued -- a smaller count only waits for a few more (older) stores.
+      if (AUX) {
+        if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
+        constexpr int kYoungLoads = NIT;
+        f32x4_t(&a)[NIT] = aux[sl & 1];
+        if (sl == 0 || sl + 1 == NSLAB) {
+          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(kYoungLoads));
+          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(kYoungLoads));
+        } else {
+          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(2 * kYoungLoads));
+          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(2 * kYoungLoads));
+        }
+      }
+      // ---- (2) read back and finish
+      const int n = ncol0 + ni * 32;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + crow;
+        const int f = fsw(r);
+        const long long m = mrow0 + mi * 32 + it * RPI;
+        float4 v[CPL / 4];
+#pragma unroll
+        for (int j = 0; j < CPL / 4; ++j) {
+          v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
+          if (W8) { v[j].x *= scol[ni][j].x; v[j].y *= scol[ni][j].y; v[j].z *= scol[ni][j].z; v[j].w *= scol[ni][j].w; }
+          if (p.bias) { v[j].x += bcol[ni][j].x; v[j].y += bcol[ni][j].y; v[j].z += bcol[ni][j].z; v[j].w += bcol[ni][j].w; }
+          if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
+        }
+        if constexpr (EPI == 2) {        // x gate: 8 bf16 values
+          const f32x4_t g = aux[sl & 1][it];
+          const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
+          v[0].x *= __uint_as_float(g0 << 16); v[0].y *= __uint_as_float(g0 & 0xffff0000u);
+          v[0].z *= __uint_as_float(g1 << 16); v[0].w *= __uint_as_float(g1 & 0xffff0000u);
+          v[1].x *= __uint_as_float(g2 << 16); v[1].y *= __uint_as_float(g2 & 0xffff0000u);
+          v[1].z *= __uint_as_float(g3 << 16); v[1].w *= __uint_as_float(g3 & 0xffff0000u);
+        }
+        if constexpr (EPI == 4) {        // + residual carried in bf16: 8 values
+          const f32x4_t g = aux[sl & 1][it];
+          const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
+          v[0].x += __uint_as_float(g0 << 16); v[0].y += __uint_as_float(g0 & 0xffff0000u);
+          v[0].z += __uint_as_float(g1 << 16); v[0].w += __uint_as_float(g1 & 0xffff0000u);
+          v[1].x += __uint_as_float(g2 << 16); v[1].y += __uint_as_float(g2 & 0xffff0000u);
+          v[1].z += __uint_as_float(g3 << 16); v[1].w += __uint_as_float(g3 & 0xffff0000u);
+        }
+        if constexpr (EPI == 3) {        // + residual: 4 fp32 values
+          const f32x4_t r4 = aux[sl & 1][it];
+          v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
+        }
+        if constexpr (WIDE8) {
+          uint4 o;
+          o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
+          *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+          if (EPI == 4 && ssq_out) {   // RMS partials of the stored (rounded) stream: 4 lanes hold the 32 columns of a slab row
+            float sq = sumsq8_bf16(o);
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
+            if ((elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;
+          }
+        } else {
+          store4(out32 + m * p.ld32 + n, v[0]);
+          if (outT) store4(outT + m * p.ldT + n, v[0]);
+          if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly, one partial per row and slab
+            float sq = sumsq4(v[0]);
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            if ((elane & 7) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;   // plain store: deterministic
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ persistent GEMM
 // Measured on MI355X (scripts/gpu_job_ablate.sh, profiles/r01_gemm_ablation.md): the 256x256 main loop is NOT bound by
 // the matrix pipe but by the global->LDS path -- with the MFMAs removed it runs no faster, ~19-25 B/clk/CU however
@@ -822,159 +991,244 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
     else main_loop(std::false_type{});
     stamp(2);
 
-    // ---------------------------------------------------------------- epilogue (32x32 fp32 slabs, private LDS region)
-    // acc[mi][ni][4q+e] = C[m0 + wm*128 + mi*32 + l31][n0 + wn*64 + ni*32 + 8q + 4hi + e]
-    // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
-    auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
-    float* stg = reinterpret_cast<float*>(smem + EPI_OFF + w * 4096);
-    constexpr bool WIDE8 = EPI == 1 || EPI == 2 || EPI == 4;      // bf16-only output, 16-byte stores
-    const T* mul = EPI == 2 ? reinterpret_cast<const T*>(p.mul) : nullptr;
-    const float* res = EPI == 3 ? p.res : nullptr;
-    float* out32 = EPI == 3 ? p.out32 : nullptr;
-    T* outT = reinterpret_cast<T*>(p.outT);
-    float* ssq_out = (EPI == 3 || EPI == 4) ? p.ssq_out : nullptr;
-    // the epilogue's per-lane address arithmetic is tile-invariant: hipcc would hoist it out of the tile loop and keep
-    // (spill) it across the main loop. An opaque copy of the lane id pins it here.
-    int elane = lane;
-    asm volatile("" : "+v"(elane));
-    const int el31 = elane & 31, ehi = elane >> 5;
-    const int fw_ = fsw(el31);
-    // Two phases per 32x32 slab: (1) the accumulators (x fused-RMSNorm row scale) go to the wave's LDS slab in MFMA
-    // layout; (2) they are read back ROW-CONTIGUOUSLY -- a lane owns 8 (bf16-only output) or 4 consecutive columns of a
-    // row, the SAME columns for every row and every mi -- and finished there: x weight scale (fp8w), + bias, activation,
-    // x gate, + residual, stores. Everything that depends on the column only (bias, fp8 scales) is therefore loaded once
-    // per tile. The per-row operands (gate / residual) are prefetched ONE SLAB AHEAD with inline-asm loads and counted
-    // `vmcnt` waits: left to hipcc, every row group waited `vmcnt(0)`, i.e. for the previous group's STORES as well (32
-    // serialised store round trips per tile, ~25 us of a 50 us tile at K = 768). VMEM operations of a wave retire in issue
-    // order; the launcher only sends M % 256 == 0, N % 256 == 0 here, so there are no bounds checks.
-    constexpr int CPL = WIDE8 ? 8 : 4;                            // columns per lane in the read-back layout
-    constexpr int LPR = 32 / CPL;                                 // lanes per slab row
-    constexpr int RPI = 64 / LPR;                                 // rows per wave-instruction (16 / 8)
-    constexpr int NIT = 32 / RPI;                                 // row groups per slab (2 / 4)
-    const int ccol = (elane % LPR) * CPL;                         // first column of this lane inside a slab
-    const int crow = elane / LPR;                                 // row of this lane inside a row group
-    const int ncol0 = n0 + wn * (NI * 32) + ccol;                 // + ni * 32
-    const int mrow0 = m0 + wm * (MI * 32) + crow;                 // + mi * 32 + it * RPI
-    float4 bcol[NI][CPL / 4], scol[NI][CPL / 4];
+    tile_epilogue_256<ACT, EPI, W8>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
+    stamp(3);
+    cv = next_valid(cv + G);
+    if (cv < 0) break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ping-pong persistent GEMM
+// Same 256x256 tile, same 32x32x16 MFMAs, same K order per accumulator (bit-identical results) and the same persistent
+// stream / epilogue as gemm_persistent_kernel, with the main loop re-scheduled after the guide's 8-phase template
+// (cdna_hip_programming.md "The 256^2 8-phase template"):
+//   * the two waves of a SIMD (w and w + 4 = the two 128-row halves wm = 0 / 1 of the tile) run ONE BARRIER APART: while
+//     one issues 8 MFMAs (a 64x32 quadrant of its 128x64 block x the whole 64-deep K-tile) under s_setprio 1, the other
+//     reads the fragments of its next quadrant and issues LDS-DMA -- the matrix pipe of a SIMD always has exactly one
+//     wave feeding it and the LDS / VMEM issue never sits in front of an MFMA;
+//   * a K-tile is staged as four 16-KiB HALF-TILES, each the set of rows ONE phase reads: B0 (W rows wn*64 + [0,32) of
+//     every wn), A0 (A rows wm*128 + [0,64)), B1, A1; quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0) with both B
+//     fragments kept in registers, so phases 1-3 read 12 / 4 / 8 ds_read_b128 and phase 4 none, and a half-tile slot is
+//     free one phase after it was read (the reading waves wait lgkmcnt(0) BEFORE their barrier);
+//   * ONE half-tile (2 LDS-DMA per wave) is requested per phase: phases 2-5 re-request the slots of the even K-tile (B0,
+//     A0, B1, A1 of the K-tile two ahead), phases 6-8 and 1 those of the odd one; `s_waitcnt vmcnt(6)` in phases 4 and 8
+//     only (never 0 while the stream lasts) retires the buffer that is read from the next phase on, three half-tiles stay
+//     in flight. Measured A/B in one process (scripts/micro/gemm_lab.hip): waiting per half-tile as late as possible
+//     (vmcnt(10) every phase, five half-tiles in flight) is 5-10 % SLOWER -- the template's throttle is the optimum; and
+//     requesting the next tile's last half-tile before the epilogue + not waiting for the epilogue's store
+//     acknowledgements in the next tile's first iteration changes nothing (+-1 %): both removed again.
+// LDS: slot(par, h) = (par * 4 + h) * 16 KiB, h = 0 B0, 1 A0, 2 B1, 3 A1; rows of 128 B with the usual XOR chunk swizzle
+// (slot rows are 32-aligned blocks of consecutive tile rows, so the conflict-free read pattern is unchanged); epilogue
+// slabs behind the ring at 128 KiB.
+// Measured on MI355X, uniform random [-1,1) operands (scripts/micro/gemm_lab.hip, profiles/r03_gemm_lab.txt): 8192^3 1.35
+// PFLOP/s against 1.10-1.13 for gemm_persistent_kernel; 131072 x 2304 x 768 bf16-out 980 vs 836 TFLOP/s.
+template <int P> struct PhaseTag { static constexpr int value = P; };
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDev p) {
+  using T = bf16_t;
+  using TL = TileL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = 128, BK = 64, MI = 4, NI = 2;
+  constexpr int SLOT = 16384, EPI_OFF = 8 * SLOT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm = w >> 2, wn = w & 3;
+  const int G = gridDim.x;
+  const int nk = p.K / BK;              // even, >= 2 (launcher)
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const char* W = reinterpret_cast<const char*>(p.W);
+
+  auto tile_at = [&](int v, int& tm, int& tn) {
+    const int idx = v >> 3;
+    const int q = idx / p.ntiles;
+    tn = idx - q * p.ntiles;
+    tm = q * 8 + (v & 7);
+  };
+  auto next_valid = [&](int v) {
+    while (v < p.vtotal) {
+      int tm, tn;
+      tile_at(v, tm, tn);
+      if (tm < p.mtiles) return v;
+      v += G;
+    }
+    return -1;
+  };
+
+  // ---- stream cursor: (tile iv, K-tile ikt) of the next half-tile request. Piece i (0 / 1) of a half-tile = slot rows
+  // [(i * 8 + w) * 8, + 8); lane -> slot row rs, 16-B position pp, global chunk pp ^ ((rs >> 1) & 7).
+  unsigned offA[2], offW[2];
+  int iv, ikt = 0;
+  auto set_ptrs = [&](int v) {
+    int tm, tn;
+    tile_at(v, tm, tn);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < CPL / 4; ++j) {
-        bcol[ni][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        scol[ni][j] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.bias) bcol[ni][j] = load4(p.bias + ncol0 + ni * 32 + 4 * j);
-        if (W8) scol[ni][j] = load4(p.wscale + ncol0 + ni * 32 + 4 * j);
-      }
-    // the column constants are needed (waited for) HERE, before the per-row prefetch starts: hipcc would otherwise wait for
-    // them at their first use with `vmcnt(0)`, i.e. for the prefetched loads issued in between as well
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < CPL / 4; ++j) {
-        if (p.bias) asm volatile("" : "+v"(bcol[ni][j].x), "+v"(bcol[ni][j].y), "+v"(bcol[ni][j].z), "+v"(bcol[ni][j].w));
-        if (W8) asm volatile("" : "+v"(scol[ni][j].x), "+v"(scol[ni][j].y), "+v"(scol[ni][j].z), "+v"(scol[ni][j].w));
-      }
-    // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
-    constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4;
-    const char* auxp = nullptr;
-    long long aux_ld = 0;                                         // bytes per row
-    if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
-    if (EPI == 3) { auxp = reinterpret_cast<const char*>(res + (long long)mrow0 * p.ldres + ncol0); aux_ld = (long long)p.ldres * 4; }
-    if (EPI == 4) { auxp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.resT) + (long long)mrow0 * p.ldresT + ncol0); aux_ld = (long long)p.ldresT * 2; }
-    f32x4_t aux[2][NIT];
-    auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {
-      const int mi = sl / NI, ni = sl % NI;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 3 ? 4 : 2);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
+    for (int i = 0; i < 2; ++i) {
+      const int rs = (i * 8 + w) * 8 + (lane >> 3);
+      const int c = ((lane & 7) ^ ((rs >> 1) & 7)) * 16;
+      offA[i] = (unsigned)(tm * 256 + (rs >> 6) * 128 + (rs & 63)) * (unsigned)(p.lda * 2) + c;     // A0 rows; A1 = + 64 rows
+      offW[i] = (unsigned)(tn * 256 + (rs >> 5) * 64 + (rs & 31)) * (unsigned)(p.ldw * 2) + c;      // B0 rows; B1 = + 32 rows
+    }
+  };
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned stepA1 = 64u * (unsigned)(p.lda * 2), stepB1 = 32u * (unsigned)(p.ldw * 2);
+  // request half-tile h of the cursor's K-tile into slot(par, h)
+  auto stage_half = [&](int par, int h) {
+    if (iv < 0) return;
+    const unsigned dst = smem_base + (unsigned)((par * 4 + h) * SLOT + w * 1024);
+    const unsigned koff = (unsigned)(ikt * RB);
+    if (h & 1) {
+      const unsigned s = koff + (h == 3 ? stepA1 : 0u);
+      glds16_asm_s(A, offA[0] + s, dst);
+      glds16_asm_s(A, offA[1] + s, dst + 8 * 1024);
+    } else {
+      const unsigned s = koff + (h == 2 ? stepB1 : 0u);
+      glds16_asm_s(W, offW[0] + s, dst);
+      glds16_asm_s(W, offW[1] + s, dst + 8 * 1024);
+    }
+  };
+  auto advance = [&]() {   // after the last half-tile (A1) of a K-tile
+    if (iv < 0) return;
+    if (++ikt == nk) {
+      ikt = 0;
+      iv = next_valid(iv + G);
+      if (iv >= 0) set_ptrs(iv);
+    }
+  };
+
+  int cv = next_valid(blockIdx.x);
+  if (cv < 0) return;
+  iv = cv;
+  set_ptrs(iv);
+  // prologue: K-tile 0 completely, K-tile 1 up to B1 (its A1 is phase 1's request)
+  stage_half(0, 0); stage_half(0, 1); stage_half(0, 2); stage_half(0, 3); advance();
+  stage_half(1, 0); stage_half(1, 1); stage_half(1, 2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // K-tile 0 has landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int arow = wm * 64 + l31;     // slot row of A fragment mi2 = 0 (+ 32 for mi2 = 1)
+  const int brow = wn * 32 + l31;     // slot row of the B fragment
+
+  while (true) {
+    int tm, tn;
+    tile_at(cv, tm, tn);
+    const int m0 = tm * TL::BM, n0 = tn * TL::BN;
+    auto stamp = [&](int slot) {
+      if (p.dbg && tid == 0) {
+        long long* d = p.dbg + (long long)cv * 8;
+        d[slot] = (long long)__builtin_readcyclecounter();
+        if (slot == 0) {
+          d[4] = (long long)__builtin_amdgcn_s_memrealtime();
+          d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+          d[7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+        if (slot == 3) d[5] = (long long)__builtin_amdgcn_s_memrealtime();
       }
     };
-    if (AUX) issue_aux(0, aux[0]);
+    stamp(0);
+    float rscv[MI];
+    int tl31 = l31;
+    asm volatile("" : "+v"(tl31));
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const float rsc = rscv[mi];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        constexpr int NSLAB = MI * NI;
-        const int sl = mi * NI + ni;
-        // ---- (1) stage
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
-          *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
-        }
-        // ---- prefetch the next slab's per-row operand, then wait for this slab's (issued one slab ago). Younger VMEM
-        // operations at that point: the stores of the previous slab (EPI 2: exactly NIT; EPI 3: at least NIT) and the NIT
-        // loads just issued -- a smaller count only waits for a few more (older) stores.
-        if (AUX) {
-          if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
-          constexpr int kYoungLoads = NIT;
-          f32x4_t(&a)[NIT] = aux[sl & 1];
-          if (sl == 0 || sl + 1 == NSLAB) {
-            if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(kYoungLoads));
-            else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(kYoungLoads));
-          } else {
-            if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(2 * kYoungLoads));
-            else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(2 * kYoungLoads));
-          }
-        }
-        // ---- (2) read back and finish
-        const int n = ncol0 + ni * 32;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int r = it * RPI + crow;
-          const int f = fsw(r);
-          const long long m = mrow0 + mi * 32 + it * RPI;
-          float4 v[CPL / 4];
-#pragma unroll
-          for (int j = 0; j < CPL / 4; ++j) {
-            v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
-            if (W8) { v[j].x *= scol[ni][j].x; v[j].y *= scol[ni][j].y; v[j].z *= scol[ni][j].z; v[j].w *= scol[ni][j].w; }
-            if (p.bias) { v[j].x += bcol[ni][j].x; v[j].y += bcol[ni][j].y; v[j].z += bcol[ni][j].z; v[j].w += bcol[ni][j].w; }
-            if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
-          }
-          if constexpr (EPI == 2) {        // x gate: 8 bf16 values
-            const f32x4_t g = aux[sl & 1][it];
-            const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
-            v[0].x *= __uint_as_float(g0 << 16); v[0].y *= __uint_as_float(g0 & 0xffff0000u);
-            v[0].z *= __uint_as_float(g1 << 16); v[0].w *= __uint_as_float(g1 & 0xffff0000u);
-            v[1].x *= __uint_as_float(g2 << 16); v[1].y *= __uint_as_float(g2 & 0xffff0000u);
-            v[1].z *= __uint_as_float(g3 << 16); v[1].w *= __uint_as_float(g3 & 0xffff0000u);
-          }
-          if constexpr (EPI == 4) {        // + residual carried in bf16: 8 values
-            const f32x4_t g = aux[sl & 1][it];
-            const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
-            v[0].x += __uint_as_float(g0 << 16); v[0].y += __uint_as_float(g0 & 0xffff0000u);
-            v[0].z += __uint_as_float(g1 << 16); v[0].w += __uint_as_float(g1 & 0xffff0000u);
-            v[1].x += __uint_as_float(g2 << 16); v[1].y += __uint_as_float(g2 & 0xffff0000u);
-            v[1].z += __uint_as_float(g3 << 16); v[1].w += __uint_as_float(g3 & 0xffff0000u);
-          }
-          if constexpr (EPI == 3) {        // + residual: 4 fp32 values
-            const f32x4_t r4 = aux[sl & 1][it];
-            v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
-          }
-          if constexpr (WIDE8) {
-            uint4 o;
-            o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
-            *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
-            if (EPI == 4 && ssq_out) {   // RMS partials of the stored (rounded) stream: 4 lanes hold the 32 columns of a slab row
-              float sq = sumsq8_bf16(o);
-              sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
-              if ((elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;
-            }
-          } else {
-            store4(out32 + m * p.ld32 + n, v[0]);
-            if (outT) store4(outT + m * p.ldT + n, v[0]);
-            if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly, one partial per row and slab
-              float sq = sumsq4(v[0]);
-              sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-              if ((elane & 7) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;   // plain store: deterministic
-            }
-          }
-        }
+      rscv[mi] = 1.0f;
+      if (EPI == 1 && p.rs_ssq) {
+        const int mr = m0 + wm * (MI * 32) + mi * 32 + tl31;
+        rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
       }
     }
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    Frag<T> fa[2][4], fb[2][4];     // A sub-tile [mi2][kk] (single buffer), B sub-tiles [b][kk] (both kept)
+    stamp(1);
+    // the 128-row halves run one barrier apart (re-joined at the end of the tile so that both run their epilogue together)
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+#ifdef VIMA_PP_PHASE_STAMPS
+    int lab_it = 0;
+#endif
+
+    auto phase = [&](auto tag) {
+      constexpr int P = decltype(tag)::value;          // 1 .. 8
+      constexpr int par = (P - 1) / 4, q = (P - 1) % 4 + 1;
+      const char* sl = smem + par * 4 * SLOT;
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- memory segment: fragments of this phase's quadrant, half-tile request(s)
+      if constexpr (q == 1) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[0][kk].template load<RB>(sl + 0 * SLOT, brow, kk, hi);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          fa[0][kk].template load<RB>(sl + 1 * SLOT, arow, kk, hi);
+          fa[1][kk].template load<RB>(sl + 1 * SLOT, arow + 32, kk, hi);
+        }
+      } else if constexpr (q == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[1][kk].template load<RB>(sl + 2 * SLOT, brow, kk, hi);
+      } else if constexpr (q == 3) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          fa[0][kk].template load<RB>(sl + 3 * SLOT, arow, kk, hi);
+          fa[1][kk].template load<RB>(sl + 3 * SLOT, arow + 32, kk, hi);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // requests: P = 2..5 -> slots (0, 0..3) ; P = 6, 7, 8, 1 -> slots (1, 0..3)
+      if constexpr (P >= 2 && P <= 5) stage_half(0, P - 2);
+      if constexpr (P == 6 || P == 7) stage_half(1, P - 6);
+      if constexpr (P == 8) stage_half(1, 2);
+      if constexpr (P == 1) stage_half(1, 3);
+      if constexpr (P == 5 || P == 1) advance();
+      // waits (counted vmcnt, never 0 while the stream lasts): phase 4 retires the odd buffer (read in phases 5-7), phase 8
+      // the even one; the three half-tiles requested last (6 LDS-DMA) stay in flight. VMEM operations retire in issue order.
+      if constexpr (q == 4) {
+        if (iv >= 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads are done -> their slot is free
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- compute segment: quadrant (mi pair, ni) x K = 64
+      constexpr int mi0 = (q <= 2) ? 0 : 2;
+      constexpr int ni = (q == 1 || q == 4) ? 0 : 1;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        acc[mi0][ni] = mma(fb[ni][kk], fa[0][kk], acc[mi0][ni]);
+        acc[mi0 + 1][ni] = mma(fb[ni][kk], fa[1][kk], acc[mi0 + 1][ni]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef VIMA_PP_PHASE_STAMPS   // clocks at the end of every phase of iterations 0 and 1 (slots 0 .. 15 behind the standard slots)
+      if (p.dbg && tid == 0 && lab_it < 4) p.dbg[(long long)p.vtotal * 8 + (long long)cv * 32 + lab_it * 4 + P - 1] = (long long)__builtin_readcyclecounter();
+#endif
+    };
+    for (int it = 0; it < nk; it += 2) {
+#ifdef VIMA_PP_PHASE_STAMPS
+      lab_it = it;
+#endif
+      phase(PhaseTag<1>{}); phase(PhaseTag<2>{}); phase(PhaseTag<3>{}); phase(PhaseTag<4>{});
+      phase(PhaseTag<5>{}); phase(PhaseTag<6>{}); phase(PhaseTag<7>{}); phase(PhaseTag<8>{});
+#ifdef VIMA_PP_PHASE_STAMPS   // clocks at the end of iterations 2 .. 17 (slots 16 .. 31)
+      if (p.dbg && tid == 0 && it >= 4 && it < 36) p.dbg[(long long)p.vtotal * 8 + (long long)cv * 32 + 14 + (it >> 1)] = (long long)__builtin_readcyclecounter();
+#endif
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp(2);
+    tile_epilogue_256<ACT, EPI, false>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
     stamp(3);
     cv = next_valid(cv + G);
     if (cv < 0) break;
@@ -1280,6 +1534,8 @@ VIMA_KNOB(gemm_small, gemm_small, "VIMA_GEMM_SMALL", g_env_small, 1)
 VIMA_KNOB(gemm_splitk, gemm_splitk, "VIMA_GEMM_SPLITK", g_env_splitk, 0)
 int g_env_wide = -1;
 VIMA_KNOB(gemm_wide, gemm_wide, "VIMA_GEMM_WIDE", g_env_wide, 0)
+int g_env_pp = -1;
+VIMA_KNOB(gemm_pp, gemm_pp, "VIMA_GEMM_PP", g_env_pp, 1)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1313,6 +1569,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
     d.ngroup = (int)ng;
   }
   dim3 grid((unsigned)(d.raster == 2 ? d.mtiles * d.ntiles : groups * 8 * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+#ifndef VIMA_GEMM_LAB
   if constexpr (sizeof(T) == 2) {
     if (a.w8) {   // fp8 weights: always the asm LDS-DMA pipeline and the vector epilogue (checked by launch_t)
       switch (a.act) {
@@ -1325,6 +1582,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
     }
   }
   if (!vec) return launch_inst<T, TL, -1, false, ASMLDS>(d, grid, st);
+#endif
   switch (a.act) {
     case ACT_NONE: return launch_inst<T, TL, ACT_NONE, true, ASMLDS>(d, grid, st);
     case ACT_RELU: return launch_inst<T, TL, ACT_RELU, true, ASMLDS>(d, grid, st);
@@ -1351,7 +1609,11 @@ int launch_persistent_w(const GemmDev& d, int grid, hipStream_t st) {
 }
 template <int ACT, int EPI>
 int launch_persistent_inst(const GemmDev& d, int grid, hipStream_t st) {
+#ifdef VIMA_GEMM_LAB
+  return launch_persistent_w<ACT, EPI, false>(d, grid, st);
+#else
   return d.wscale ? launch_persistent_w<ACT, EPI, true>(d, grid, st) : launch_persistent_w<ACT, EPI, false>(d, grid, st);
+#endif
 }
 
 int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
@@ -1384,6 +1646,55 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
     case ACT_GELU * 8 + 2: return launch_persistent_inst<ACT_GELU, 2>(d, grid, st);
     case ACT_QUICKGELU * 8 + 1: return launch_persistent_inst<ACT_QUICKGELU, 1>(d, grid, st);
     default: return -1;   // no specialised instantiation (the all-runtime form spills): one-tile-per-workgroup kernel
+  }
+}
+
+template <int ACT, int EPI>
+int launch_pp_inst(const GemmDev& d, int grid, hipStream_t st) {
+  constexpr int SMEM = 8 * 16384 + TileL::NW * 4096;   // eight half-tile slots + epilogue slabs = 160 KiB
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<ACT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
+  return (int)hipGetLastError();
+}
+
+// ping-pong persistent kernel (option gemm_pp): same eligibility as launch_persistent plus an even number of K-tiles and
+// bf16 weights; returns -1 when the problem does not fit it (caller falls back)
+int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (a.w8 || (a.K / 64) % 2 != 0) return -1;
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cu = n / 8 * 8;
+  }
+  d.mtiles = (d.M + TileL::BM - 1) / TileL::BM;
+  d.ntiles = (d.N + TileL::BN - 1) / TileL::BN;
+  d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
+  d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
+  const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
+  int epi = 0;
+  if (a.rb == 0) {
+    if (d.wide8 && !a.mul && !a.res && !a.resT && !a.ssq_out) epi = 1;
+    else if (d.wide8 && a.mul && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
+    else if (!d.wide8 && a.res && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;
+    else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
+  }
+  if (a.resT && epi != 4) return -1;
+  switch (a.act * 8 + epi) {
+    case ACT_NONE * 8 + 1: return launch_pp_inst<ACT_NONE, 1>(d, grid, st);
+    case ACT_NONE * 8 + 3: return launch_pp_inst<ACT_NONE, 3>(d, grid, st);
+    case ACT_NONE * 8 + 4: return launch_pp_inst<ACT_NONE, 4>(d, grid, st);
+    case ACT_RELU * 8 + 1: return launch_pp_inst<ACT_RELU, 1>(d, grid, st);
+    case ACT_GELU * 8 + 2: return launch_pp_inst<ACT_GELU, 2>(d, grid, st);
+    case ACT_QUICKGELU * 8 + 1: return launch_pp_inst<ACT_QUICKGELU, 1>(d, grid, st);
+    default: return -1;
   }
 }
 
@@ -1560,11 +1871,18 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
         a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
         (long long)a.N * a.ldw * (long long)esw < (1LL << 32)) {
+      if (gemm_pp(a.tune)) {
+        const int e = launch_pp(d, a, st);
+        if (e >= 0) return e;
+      }
       const int e = launch_persistent(d, a, st);
       if (e >= 0) return e;
     }
     if (large) return launch_tile<T, TileL, true>(d, a, v, st);
   }
+#ifdef VIMA_GEMM_LAB
+  return (int)hipErrorInvalidValue;
+#else
   if constexpr (sizeof(T) == 2) {
     // Underfilled 128x128 grids (batch 1 .. 32: M = 8 .. 512) are bound by how fast ONE workgroup walks its K dimension
     // (a 32-KiB slice per ~1400 clocks, most of the A tile being padding rows): smaller tiles move fewer bytes per slice
@@ -1580,12 +1898,17 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   }
   if (gemm_variant(a.tune) == 1 || a.w8) return launch_tile<T, TileS, true>(d, a, v, st);
   return launch_tile<T, TileS, false>(d, a, v, st);
+#endif
 }
 
 }  // namespace
 
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st) {
+#ifdef VIMA_GEMM_LAB
+  return is_bf16 ? launch_t<bf16_t>(a, st) : (int)hipErrorInvalidValue;
+#else
   return is_bf16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
+#endif
 }
 size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16) {
   const SplitPlan sp = splitk_plan(a, is_bf16);

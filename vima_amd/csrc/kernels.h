@@ -15,6 +15,7 @@ struct Tuning {
   int gemm_persist = -1;   // VIMA_GEMM_PERSIST  1 = large bf16 GEMMs on the persistent kernel (default)
   int gemm_small = -1;     // VIMA_GEMM_SMALL    1 = 64x64 / 32x64 tiles for underfilled grids (default)
   int gemm_wide = -1;      // VIMA_GEMM_WIDE     1 = 256x384 persistent tile where N % 384 == 0 (bf16-out / bf16-residual epilogues)
+  int gemm_pp = -1;        // VIMA_GEMM_PP       1 = ping-pong (8-phase) main loop on the persistent 256x256 kernel (default), 0 = the round-2 loop
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
