@@ -1041,10 +1041,19 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
   const T* A = reinterpret_cast<const T*>(p.A);
   const char* W = reinterpret_cast<const char*>(p.W);
 
+  // virtual tile id v -> (tm, tn); workgroup b takes v = b, b + G, ... (G % 8 == 0), so v & 7 is its XCD. Within an XCD the
+  // n-tiles are walked in groups of `ngroup` (= ntiles: one group): the XCD takes ALL its A panels through one group of W
+  // panels -- small enough to stay in its 4-MiB L2 -- before it moves to the next group (the A panels are then fetched once
+  // per group; with one group the W panels of a wide N are re-streamed from beyond L2 for every A panel).
   auto tile_at = [&](int v, int& tm, int& tn) {
     const int idx = v >> 3;
-    const int q = idx / p.ntiles;
-    tn = idx - q * p.ntiles;
+    const int mtx = (p.mtiles + 7) >> 3;                // A panels per XCD (incl. padding panels)
+    const int per_group = mtx * p.ngroup;
+    const int g = idx / per_group;
+    const int rem = idx - g * per_group;
+    const int ng = min(p.ngroup, p.ntiles - g * p.ngroup);   // the last group may be smaller
+    const int q = rem / ng;
+    tn = g * p.ngroup + (rem - q * ng);
     tm = q * 8 + (v & 7);
   };
   auto next_valid = [&](int v) {
@@ -1676,7 +1685,21 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.mtiles = (d.M + TileL::BM - 1) / TileL::BM;
   d.ntiles = (d.N + TileL::BN - 1) / TileL::BN;
   d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
-  d.raster = 0; d.ngroup = 1; d.epi_lds = 1;
+  d.raster = 0; d.epi_lds = 1;
+  d.ngroup = d.ntiles;
+  {   // W panels of one n-group <= `VIMA_GEMM_NGROUP_KB` (default 2560 KiB) so that they stay resident in an XCD's L2
+    static int kb = -1;
+    if (kb < 0) kb = env_int("VIMA_GEMM_NGROUP_KB", 2560);
+    const long long panel = (long long)TileL::BN * a.K * 2;
+    // only for short K: every extra group re-reads the whole A matrix (measured: 131072 x 768 x 3072 in three groups
+    // 1167 -> 999 TFLOP/s; 131072 x 3072 x 768 in two groups: same time, W no longer re-streamed from beyond L2)
+    if (kb > 0 && a.K <= 1536 && (long long)d.ntiles * panel > (long long)kb * 1024) {
+      int ng = (int)((long long)kb * 1024 / panel);
+      if (ng < 1) ng = 1;
+      const int groups = (d.ntiles + ng - 1) / ng;
+      d.ngroup = (d.ntiles + groups - 1) / groups;    // equal groups
+    }
+  }
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
   int epi = 0;
