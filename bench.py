@@ -48,16 +48,25 @@ def flops_per_sample(E, N, Lp, n_prompt_obj, Q, T):
     return prompt + step, step
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant (GEMM) kernel from the committed rocprofv3 PMC passes (profiles/): the
-    counters need their own profiler runs (FETCH_SIZE and WRITE_SIZE do not fit one pass), so bench.py reports the
-    last committed measurement of this same command rather than collecting it live. None if absent."""
+def pmc_traffic(kernel=None):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/): the counters need their own profiler runs
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass), so bench.py reports the last committed measurement of this same command
+    rather than collecting it live. `kernel` = a rocprofv3 kernel name: that kernel's own bytes per launch (newer summaries
+    carry a per-kernel table); without it, or for older summaries, the average over all bf16 GEMM launches. None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
     try:
-        return round(float(json.load(open(files[-1]))["gemm_bf16_bytes_per_launch"]), 1)
+        d = json.load(open(files[-1]))
+        if kernel is not None:
+            pk = d.get("per_kernel", {})
+            key = kernel.replace(" ", "")
+            for name, v in pk.items():
+                if name.replace(" ", "") == key:
+                    return round(float(v["bytes_per_launch"]), 1)
+            return None
+        return round(float(d["gemm_bf16_bytes_per_launch"]), 1)
     except Exception:
         return None
 
@@ -340,6 +349,7 @@ def main():
     pol.prof_enable(True)
     step()
     torch.cuda.synchronize(dev)
+    gk = pol.prof_read_gemm_kernels()           # per KERNEL (the launcher's choice), before the class read resets the records
     prof = pol.prof_read_ex()
     pol.prof_enable(False)
 
@@ -364,13 +374,20 @@ def main():
     k_res = klass(g3, "vima::gemm_persistent_kernel<ACT_NONE, EPI 4 | EPI 3> (+ gemm_kernel fallbacks): the residual GEMMs (T5 o / wo and ViT "
                       "out_proj / c_proj with the stream in bf16: read + write 2 B per element, RMS partials; decoder: fp32 stream)")
     k_plain = klass(g0, "vima::gemm_persistent_kernel<*, EPI 1|2> / vima::gemm_kernel: all other GEMM launches (bf16-only output)")
-    dominant = k_res if g3["ms"] >= g0["ms"] else k_plain
     gemm_ms = g0["ms"] + g3["ms"]
     gemm_tflops = (g0["flops"] + g3["flops"]) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    roofline = dict(dominant)
+    # the DOMINANT KERNEL (most time in the step), under the name rocprofv3 prints for it, with its own algorithmic flops /
+    # bytes and its own counter traffic
+    dom_name = max(gk, key=lambda k: gk[k]["ms"]) if gk else None
+    roofline = klass(gk[dom_name], dom_name) if dom_name else dict(k_res if g3["ms"] >= g0["ms"] else k_plain)
     roofline.update({
-        "traffic": pmc_traffic(),
-        "other_gemm_class": k_res if dominant is k_plain else k_plain,
+        "traffic": pmc_traffic(dom_name) if dom_name else pmc_traffic(),
+        "traffic_all_gemm_launches": pmc_traffic(),
+        "gemm_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
+                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0,
+                             "algorithmic_mb_per_launch": round(v["bytes"] / max(v["launches"], 1) / 1e6, 1)}
+                         for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+        "gemm_classes": [k_plain, k_res],
         "all_gemm": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
                      "launches_per_step": g0["launches"] + g3["launches"], "ms_per_step": round(gemm_ms, 3)},
         "gemm_ms_per_step": round(gemm_ms, 3), "attention_ms_per_step": round(prof["attention"]["ms"], 3),
@@ -379,14 +396,31 @@ def main():
         "whole_step_frac": round(B * cold / (ms_per_step * 1e-3) / 1e12 / peak, 4),
         "note": "per-class numbers: HIP events around every launch in a separate pass with dual_stream=0 (un-overlapped kernel "
                 "durations, what rocprofv3 --kernel-trace reports for the committed profile); achieved = ALGORITHMIC flops or bytes "
-                "(each operand / output / epilogue input once) over that time; `bound` from the class's flop/byte vs the 312 FLOP/B "
-                "machine balance; `traffic` = HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (all bf16 GEMM launches). "
+                "(each operand / output / epilogue input once) over that time; `bound` from the kernel's flop/byte vs the 312 FLOP/B "
+                "machine balance; `kernel` = the kernel with the most time in the step; `traffic` = ITS HBM bytes per launch from the "
+                "committed rocprofv3 PMC passes (`traffic_all_gemm_launches`: average over all bf16 GEMM launches). "
                 "whole_step_*: the 49.09 TFLOP algorithmic numerator over the timed wall clock (the last ViT block is computed for the "
                 "cls token only -- executed GEMM FLOPs are ~6 % below the algorithmic count)",
     })
 
+    # secondary rooflines: the WARM step (prompt reused: obs ViT + decoder against the cached prompt K/V +
+    # action head) and the incremental env step are bound by the matrix pipe on their ~1.4 TFLOP and by HBM on the per-layer
+    # K/V stream (B x Lp x 2E bf16 per decoder layer) + the weights; both bounds are reported, the larger one is the roofline
+    def small_roofline(ms, flops):
+        if not (ms == ms and ms > 0):
+            return None
+        kv_bytes = cfg.xf_n_layers * B * args.prompt_len * 2 * cfg.embed_dim * 2.0
+        w_bytes = {"bf16": 676e6, "fp8w": 370e6, "fp32": 1352e6}[args.precision] * 0.45      # decoder + obs ViT + heads (no T5)
+        t_mfma, t_hbm = flops / (peak * 1e12) * 1e3, (kv_bytes + w_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
+        return {"bound": "hbm" if t_hbm > t_mfma else "mfma", "mfma_ms": round(t_mfma, 4), "hbm_ms": round(t_hbm, 4),
+                "roofline_ms": round(max(t_mfma, t_hbm), 4), "frac": round(max(t_mfma, t_hbm) / ms, 4),
+                "algorithmic_tflop": round(flops / 1e12, 3), "kv_stream_mb": round(kv_bytes / 1e6, 1)}
+
+    warm_roof = small_roofline(warm_ms, B * warm)
+    inc_roof = small_roofline(inc_ms, B * warm)
+
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:          # timed on rank 0's host cores, outside the timed region, for every N
         cpu_baseline = run_cpu_baseline(cfg, sd, n_seg, args.qv, args.cpu_batch, B, words=args.words)
 
     if rank == 0:
@@ -402,6 +436,7 @@ def main():
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),
                        "warm_ms_per_step": round(warm_ms, 3) if warm_ms == warm_ms else None, "warm_steps_per_s": round(world * 1e3 / warm_ms, 2) if warm_ms == warm_ms else None,
                        "incremental_env_step_ms": round(inc_ms, 3) if inc_ms == inc_ms else None,
+                       "warm_roofline": warm_roof, "incremental_roofline": inc_roof,
                        "secondary_cold": secondary},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

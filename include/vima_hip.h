@@ -49,8 +49,10 @@ typedef struct VimaConfig {
   int32_t xattn_n_heads;
   int32_t xattn_n_positions;
   int32_t n_positions;
-  int32_t precision; /* VIMA_PRECISION_*: operand type of the matrix-core GEMMs / attention (accumulation, residual
-                        stream, LayerNorm and softmax statistics are always fp32) */
+  int32_t precision; /* VIMA_PRECISION_*: operand type T of the matrix-core GEMMs / attention. Accumulation, LayerNorm /
+                        RMSNorm and softmax statistics are always fp32; the DECODER's residual stream is fp32; the residual
+                        streams of the T5 stack and of the ViT are carried in T as well when option "stream_T" is 1 (the
+                        default: bf16 streams in the BF16 / FP8W precisions, fp32 in FP32) and in fp32 when it is 0. */
   int32_t policy_kind; /* VIMA_POLICY_* (ABI version 3; 0 = VIMAPolicy) */
 } VimaConfig;
 
@@ -209,9 +211,29 @@ void vima_fp8_e4m3_encode(const float* src, uint8_t* dst, int64_t n);
 int vima_t5_bucket(int relative_position);
 
 /* ---- tuning / instrumentation ---------------------------------------------------------------------------------- */
-/* key in {"attn_impl" (0 generic, 1 mfma), "attn_split", "attn4_min_lq", "gemm_variant" (0 builtin LDS-DMA, 1 asm LDS-DMA),
- *         "gemm_tile" (0 auto, 1 128x128, 2 256x256 8 waves, 3 256x128 ring, 4 256x256 4 waves), "gemm_raster",
- *         "gemm_epi" (1 LDS-transposed epilogue), "vit_chunk" (crops), "vit_prune_last", "dual_stream"} */
+/* Per-handle options (every key vima_set_option accepts; unknown keys fail). Defaults in brackets.
+ *   kernel selection, GEMM:  "gemm_variant" [1] 1 inline-asm LDS-DMA pipeline, 0 compiler-tracked builtin (128x128 tile only)
+ *                            "gemm_tile"    [0] 0 auto, 1 force 128x128, 2 force 256x256, 7 force 32x64, 8 force 64x64
+ *                            "gemm_persist" [1] large bf16 GEMMs on the persistent 256x256 kernels
+ *                            "gemm_pp"      [1] ping-pong (8-phase) main loop of the persistent kernel (0: the round-2 loop)
+ *                            "gemm_wide"    [0] 256x384 persistent tile where N % 384 == 0
+ *                            "gemm_small"   [1] 64x64 / 32x64 tiles for grids that would leave most CUs idle
+ *                            "gemm_splitk"  [0] deterministic two-pass split-K for underfilled grids with K >= 1536
+ *                            "gemm_raster"  [0] tile order of the one-tile-per-workgroup kernels: 0 XCD x n-walk, 1 XCD x
+ *                                               resident n-group, 2 row-major
+ *                            "gemm_epi"     [1] LDS-transposed row-contiguous epilogue (0: direct per-lane stores)
+ *   kernel selection, attention: "attn_impl" [1] 1 MFMA flash kernels, 0 exact generic kernel
+ *                            "attn_split"   [1] split-key 4-wave kernel for <= 32 queries
+ *                            "attn4_min_lq" [64] query count from which the 4-wave LDS-shared flash kernel is used
+ *                            "attn_qg"      [2] 32-query groups per wave in that kernel (2 from 256 queries on)
+ *   numerics / fusion:       "stream_T"     [1] T5 / ViT residual streams carried in the operand type (see VimaConfig)
+ *                            "t5_fuse_rms"  [1] T5 RMSNorms folded into the neighbouring GEMMs
+ *                            "vit_prune_last" [1] last ViT block evaluated for the cls row only (identical values)
+ *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
+ *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
+ *                            "vit_chunk"    [16384] crops per ViT pass
+ *   test / instrumentation:  "op_bf16_out", "op_stream_T" (route vima_op_linear through the bf16-output / bf16-residual
+ *                            epilogues), "gemm_dbg_ptr", "attn_dbg_ptr" (device buffers for shader-clock stamps, 0 = off) */
 int vima_set_option(VimaHandle* h, const char* key, int64_t value);
 /* When enabled every kernel launch is bracketed by HIP events on the launch stream and attributed to a class:
  * 0 = GEMM, 1 = attention, 2 = other. vima_prof_read synchronises and returns per class
@@ -222,6 +244,12 @@ int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], dou
  * epilogue input counted once): class 0 = GEMMs without, class 3 = GEMMs with an fp32-residual epilogue (read fp32
  * residual, write the fp32 stream [+ operand-type copy + RMS partials]: the HBM-heavy ones), 1 = attention, 2 = other. */
 int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]);
+/* The GEMM launches recorded since vima_prof_enable, grouped by the KERNEL the launcher chose: ids[i] = kind * 1000 +
+ * (activation + 1) * 10 + epilogue, kind 1 gemm_pp_kernel<ACT, EPI>, 2 gemm_persistent_kernel<ACT, EPI>, 3 gemm_wide_kernel,
+ * 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile, 8 two-pass split-K; per kernel the summed milliseconds,
+ * launches, algorithmic FLOPs and algorithmic HBM bytes. Returns the number of kernels (<= max_n) or a negative error; does
+ * NOT reset the records (call it before vima_prof_read / vima_prof_read_ex). */
+int vima_prof_read_gemm_kernels(VimaHandle* h, int max_n, int32_t* ids, double* ms, int64_t* launches, double* flops, double* bytes);
 /* bytes currently held by the workspace arena */
 int64_t vima_workspace_bytes(VimaHandle* h);
 /* hipGraph replay (vima_set_option(h, "graphs", 1)): the per-env-step entry points (vima_obs_encode, vima_decode,

@@ -31,7 +31,8 @@ def main():
         nf, af, tf = f.get(k, (0, 0.0, 0.0))
         nw, aw, tw = w.get(k, (0, 0.0, 0.0))
         rows.append((short(k), nf, af, aw, (2 * af + aw) * 1024))
-    gem = [r for r in rows if "gemm_kernel<unsigned short" in r[0] or "gemm_persistent_kernel" in r[0]]
+    gem = [r for r in rows if "gemm_kernel<unsigned short" in r[0] or "gemm_persistent_kernel" in r[0] or "gemm_pp_kernel" in r[0]
+           or "gemm_wide_kernel" in r[0]]
     n = sum(r[1] for r in gem)
     gem_bytes = sum(r[1] * r[4] for r in gem) / max(n, 1)
     with open(out_md, "w") as fh:
@@ -40,8 +41,9 @@ def main():
         fh.write("| kernel | launches | avg FETCH_SIZE KiB | avg WRITE_SIZE KiB | corrected MB / launch |\n|---|---|---|---|---|\n")
         for r in rows[:25]:
             fh.write(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.0f} | {r[4] / 1e6:.1f} |\n")
-        fh.write(f"\nAll bf16 GEMM instantiations (`gemm_kernel<bf16,...>` and `gemm_persistent_kernel`): {n} launches, {gem_bytes / 1e6:.1f} MB per launch on average.\n")
+        fh.write(f"\nAll bf16 GEMM instantiations (`gemm_kernel<bf16,...>`, `gemm_pp_kernel`, `gemm_persistent_kernel`, `gemm_wide_kernel`): {n} launches, {gem_bytes / 1e6:.1f} MB per launch on average.\n")
     json.dump({"gemm_bf16_launches": n, "gemm_bf16_bytes_per_launch": gem_bytes,
+               "per_kernel": {r[0]: {"launches": r[1], "bytes_per_launch": r[4]} for r in rows[:40]},
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0",
                "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950 half-count)"}, open(out_json, "w"), indent=1)
     print("gemm bf16:", n, "launches,", gem_bytes / 1e6, "MB/launch")

@@ -64,6 +64,8 @@ PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_double)]),
     "vima_prof_read_ex": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "vima_prof_read_gemm_kernels": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
+                                                   ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "vima_workspace_bytes": (c_i64, [vp]),
     "vima_graph_stats": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "vima_crop_objects": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,

@@ -610,9 +610,12 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // ------------------------------------------------------------------------------------------------ 256x256 tile epilogue
 // Shared by the persistent kernels (gemm_persistent_kernel, gemm_pp_kernel): the wave's 128x64 accumulator block goes
 // through a wave-private 4 KiB LDS slab (32x32 fp32, XOR-swizzled) and is finished row-contiguously.
-template <int ACT, int EPI, bool W8>
-__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
-                                                  int lane, int m0, int n0, int wm, int wn) {
+// HAS_BIAS / HAS_RS (fused-RMSNorm row scale) are compile-time here: as runtime flags hipcc turned the conditional adds into
+// v_pk_add + one v_cndmask per value and kept the x rsc multiply -- 256 of the 321 VALU instructions per wave of a
+// bias-less, scale-less epilogue (every T5 GEMM) did nothing, and the epilogue is VALU-issue-bound (2 waves per SIMD).
+template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS>
+__device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
+                                                       int lane, int m0, int n0, int wm, int wn) {
   using T = bf16_t;
   constexpr int MI = 4, NI = 2;
   const int act = ACT >= 0 ? ACT : p.act;
@@ -656,7 +659,7 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
     for (int j = 0; j < CPL / 4; ++j) {
       bcol[ni][j] = make_float4(0.f, 0.f, 0.f, 0.f);
       scol[ni][j] = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (p.bias) bcol[ni][j] = load4(p.bias + ncol0 + ni * 32 + 4 * j);
+      if constexpr (HAS_BIAS) bcol[ni][j] = load4(p.bias + ncol0 + ni * 32 + 4 * j);
       if (W8) scol[ni][j] = load4(p.wscale + ncol0 + ni * 32 + 4 * j);
     }
   // the column constants are needed (waited for) HERE, before the per-row prefetch starts: hipcc would otherwise wait for
@@ -665,7 +668,7 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
   for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int j = 0; j < CPL / 4; ++j) {
-      if (p.bias) asm volatile("" : "+v"(bcol[ni][j].x), "+v"(bcol[ni][j].y), "+v"(bcol[ni][j].z), "+v"(bcol[ni][j].w));
+      if constexpr (HAS_BIAS) asm volatile("" : "+v"(bcol[ni][j].x), "+v"(bcol[ni][j].y), "+v"(bcol[ni][j].z), "+v"(bcol[ni][j].w));
       if (W8) asm volatile("" : "+v"(scol[ni][j].x), "+v"(scol[ni][j].y), "+v"(scol[ni][j].z), "+v"(scol[ni][j].w));
     }
   // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
@@ -695,7 +698,8 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
       // ---- (1) stage
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = make_float4(acc[mi][ni][4 * q] * rsc, acc[mi][ni][4 * q + 1] * rsc, acc[mi][ni][4 * q + 2] * rsc, acc[mi][ni][4 * q + 3] * rsc);
+        float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+        if constexpr (HAS_RS) { v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc; }
         *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
       }
       // ---- prefetch the next slab's per-row operand, then wait for this slab's (issued one slab ago). Younger VMEM
@@ -725,7 +729,7 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
         for (int j = 0; j < CPL / 4; ++j) {
           v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
           if (W8) { v[j].x *= scol[ni][j].x; v[j].y *= scol[ni][j].y; v[j].z *= scol[ni][j].z; v[j].w *= scol[ni][j].w; }
-          if (p.bias) { v[j].x += bcol[ni][j].x; v[j].y += bcol[ni][j].y; v[j].z += bcol[ni][j].z; v[j].w += bcol[ni][j].w; }
+          if constexpr (HAS_BIAS) { v[j].x += bcol[ni][j].x; v[j].y += bcol[ni][j].y; v[j].z += bcol[ni][j].z; v[j].w += bcol[ni][j].w; }
           if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
         }
         if constexpr (EPI == 2) {        // x gate: 8 bf16 values
@@ -768,6 +772,25 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
         }
       }
     }
+  }
+}
+
+template <int ACT, int EPI, bool W8>
+__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
+                                                  int lane, int m0, int n0, int wm, int wn) {
+  const bool hb = p.bias != nullptr;                                   // kernel arguments: wave-uniform branches
+  const bool hr = (EPI == 0 || EPI == 1) && p.rs_ssq != nullptr;
+  if constexpr (EPI == 0 || EPI == 1) {
+    if (hb) {
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, true, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    } else {
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, false, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    }
+  } else {
+    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    else tile_epilogue_256_impl<ACT, EPI, W8, false, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
   }
 }
 
@@ -1840,6 +1863,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (sp.S > 1 && ok4 && a.splitk_ws_bytes >= (size_t)sp.S * MN * sizeof(float) && aligned_to(a.splitk_ws, 16)) {
       GemmArgs p1;
       p1.A = a.A; p1.lda = a.lda; p1.W = a.W; p1.ldw = a.ldw; p1.M = a.M; p1.N = a.N; p1.K = sp.Ks;
+      if (a.kernel_id) *a.kernel_id = 8000 + (a.act + 1) * 10;
       p1.tune = a.tune; p1.batch = sp.S; p1.bsA = sp.Ks; p1.bsW = sp.Ks; p1.out32 = a.splitk_ws; p1.ld32 = a.N; p1.bs32 = MN;
       if (int e = launch_t<T>(p1, st)) return e;
       const long long work = (long long)a.M * (a.N / 4);
@@ -1888,20 +1912,21 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (gemm_tile(a.tune) >= 7) large = false;
     if (large && gemm_wide(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {
       const int e = launch_wide(d, a, st);
-      if (e >= 0) return e;
+      if (e >= 0) { if (a.kernel_id) *a.kernel_id = 3000 + (a.act + 1) * 10 + (a.resT ? 4 : 1); return e; }
     }
     if (large && (gemm_tile(a.tune) == 0 || gemm_tile(a.tune) == 2) && gemm_persist(a.tune) && a.batch <= 1 &&
         a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
         (long long)a.N * a.ldw * (long long)esw < (1LL << 32)) {
+      const int epi_id = a.resT ? 4 : (a.res ? 3 : (a.mul ? 2 : 1));
       if (gemm_pp(a.tune)) {
         const int e = launch_pp(d, a, st);
-        if (e >= 0) return e;
+        if (e >= 0) { if (a.kernel_id) *a.kernel_id = 1000 + (a.act + 1) * 10 + epi_id; return e; }
       }
       const int e = launch_persistent(d, a, st);
-      if (e >= 0) return e;
+      if (e >= 0) { if (a.kernel_id) *a.kernel_id = 2000 + (a.act + 1) * 10 + epi_id; return e; }
     }
-    if (large) return launch_tile<T, TileL, true>(d, a, v, st);
+    if (large) { if (a.kernel_id) *a.kernel_id = 4000 + (a.act + 1) * 10; return launch_tile<T, TileL, true>(d, a, v, st); }
   }
 #ifdef VIMA_GEMM_LAB
   return (int)hipErrorInvalidValue;
@@ -1913,12 +1938,14 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     // on the choice.
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
     if (v && gemm_tile(a.tune) == 0 && gemm_small(a.tune) && t128 < 128) {
+      if (a.kernel_id) *a.kernel_id = (a.M <= 32 ? 7000 : 6000) + (a.act + 1) * 10;
       if (a.M <= 32) return launch_tile<T, TileXS, true>(d, a, v, st);
       return launch_tile<T, Tile64, true>(d, a, v, st);
     }
     if (gemm_tile(a.tune) == 7 && v) return launch_tile<T, TileXS, true>(d, a, v, st);
     if (gemm_tile(a.tune) == 8 && v) return launch_tile<T, Tile64, true>(d, a, v, st);
   }
+  if (a.kernel_id) *a.kernel_id = 5000 + (a.act + 1) * 10;
   if (gemm_variant(a.tune) == 1 || a.w8) return launch_tile<T, TileS, true>(d, a, v, st);
   return launch_tile<T, TileS, false>(d, a, v, st);
 #endif

@@ -147,7 +147,7 @@ struct Arena {          // stream-ordered bump allocator; chunks are only releas
   }
 };
 
-struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; };
+struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; int kid = 0; };   // kid: GemmArgs::kernel_id of a GEMM launch
 
 }  // namespace
 
@@ -648,8 +648,11 @@ struct Run {
                                  (a.res ? mn * 4 : 0) + (a.resT ? mn * es : 0) + (a.mul ? mn * es : 0) + (a.ssq_out ? (double)a.M * (a.N / 32) * 4 : 0));
       prof_begin(((a.res && a.out32) || a.resT) ? 3 : 0, 2.0 * a.M * (double)a.N * a.K * nb, bytes);
     }
+    int kid = 0;
+    a.kernel_id = &kid;
     int e = launch_gemm(a, h->bf16, st);
     prof_end();
+    if (h->prof && !h->recs.empty()) h->recs.back().kid = kid;
     if (e) err = fail(std::string("gemm launch failed: ") + hipGetErrorString((hipError_t)e) + " (M=" + std::to_string(a.M) +
                       " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + ")", e);
     return err;
@@ -1302,6 +1305,35 @@ int vima_prof_enable(VimaHandle* h, int on) {
   h->recs.clear();
   h->ev_used = 0;
   return 0;
+}
+
+int vima_prof_read_gemm_kernels(VimaHandle* h, int max_n, int32_t* ids, double* ms, int64_t* launches, double* flops, double* bytes) {
+  if (!h || max_n < 0 || (max_n > 0 && (!ids || !ms || !launches || !flops || !bytes))) {
+    (void)fail("vima_prof_read_gemm_kernels: bad argument");
+    return -1;
+  }
+  std::map<int, int> slot;
+  int n = 0;
+  for (auto& r : h->recs) {
+    if (r.cls != 0 && r.cls != 3) continue;
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+      (void)fail("vima_prof_read_gemm_kernels: event query failed");
+      return -1;
+    }
+    auto it = slot.find(r.kid);
+    int i;
+    if (it == slot.end()) {
+      if (n >= max_n) continue;
+      i = n++;
+      slot[r.kid] = i;
+      ids[i] = r.kid; ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0;
+    } else {
+      i = it->second;
+    }
+    ms[i] += t; launches[i] += 1; flops[i] += r.flops; bytes[i] += r.bytes;
+  }
+  return n;
 }
 
 int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]) {

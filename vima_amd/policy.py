@@ -511,5 +511,30 @@ class VIMAPolicy(nn.Module):
         names = ("gemm", "attention", "other", "gemm_residual")
         return {names[i]: {"ms": ms[i], "launches": int(n[i]), "flops": fl[i], "bytes": by[i]} for i in range(4)}
 
+    _GEMM_KINDS = {1: "vima::gemm_pp_kernel", 2: "vima::gemm_persistent_kernel", 3: "vima::gemm_wide_kernel",
+                   4: "vima::gemm_kernel<Tile<256, 256>>", 5: "vima::gemm_kernel<Tile<128, 128>>", 6: "vima::gemm_kernel<Tile<64, 64>>",
+                   7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)"}
+
+    def prof_read_gemm_kernels(self):
+        """GEMM launches recorded since prof_enable(True), grouped by the kernel the launcher chose (call BEFORE prof_read /
+        prof_read_ex, which reset the records) -> {kernel name as rocprofv3 prints it: {ms, launches, flops, bytes}}."""
+        n = 64
+        ids = (ctypes.c_int32 * n)()
+        ms = (ctypes.c_double * n)()
+        ln = (ctypes.c_int64 * n)()
+        fl = (ctypes.c_double * n)()
+        by = (ctypes.c_double * n)()
+        k = self._lib.vima_prof_read_gemm_kernels(self._handle, n, ids, ms, ln, fl, by)
+        if k < 0:
+            _lib.check(1)
+        out = {}
+        for i in range(k):
+            kind, rest = divmod(int(ids[i]), 1000)
+            act, epi = divmod(rest, 10)
+            base = self._GEMM_KINDS.get(kind, f"gemm kind {kind}")
+            name = f"{base}<{act - 1}, {epi}>" if kind in (1, 2, 3) else f"{base} act {act - 1}"
+            out[name] = {"ms": ms[i], "launches": int(ln[i]), "flops": fl[i], "bytes": by[i]}
+        return out
+
     def workspace_bytes(self) -> int:
         return int(self._lib.vima_workspace_bytes(self._handle)) if self._handle is not None else 0
