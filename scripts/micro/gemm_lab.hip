@@ -73,6 +73,7 @@ int main(int argc, char** argv) {
       if (nm == "persist") {}
       else if (nm == "pp") v.t.gemm_pp = 1;
       else if (nm == "tile") v.t.gemm_persist = 0;
+      else if (nm == "fp8") v.t.gemm_pp = 1;     // fp8 e4m3 A and W, v_mfma_scale_f32_32x32x64_f8f6f4 (own operands / reference)
       else if (nm == "wide") v.t.gemm_wide = 1;
       else { printf("unknown variant %s\n", nm.c_str()); return 1; }
       vars.push_back(v);
@@ -99,9 +100,29 @@ int main(int argc, char** argv) {
   if (stamps) { CK(hipMalloc(&dbg, (size_t)nblk * 40 * 8)); }
   CK(hipDeviceSynchronize());
 
+  // fp8 operands: random finite e4m3 bytes (exponent field < 15 or mantissa < 7), per-channel weight scales, one activation scale
+  uint8_t *A8 = nullptr, *W8 = nullptr;
+  float* wsc = nullptr;
+  const float asc = 0.037f;
+  bool any8 = false;
+  for (auto& v : vars) any8 |= v.name == "fp8";
+  std::vector<uint8_t> hA8, hW8;
+  std::vector<float> hws;
+  if (any8) {
+    hA8.resize((size_t)M * K); hW8.resize((size_t)N * K); hws.resize(N);
+    auto fill8 = [&](std::vector<uint8_t>& v) {
+      for (auto& b : v) { uint8_t x = (uint8_t)(rnd() >> 11); if ((x & 0x7f) == 0x7f) x ^= 1; if ((x & 0x78) == 0x78) x &= 0xbf; b = x; }   // |x| <= 240: no NaN
+    };
+    fill8(hA8); fill8(hW8);
+    for (auto& x : hws) x = 0.01f + 0.02f * (float)(rnd() >> 8) / 16777216.0f;
+    CK(hipMalloc(&A8, hA8.size())); CK(hipMalloc(&W8, hW8.size())); CK(hipMalloc(&wsc, (size_t)N * 4));
+    CK(hipMemcpy(A8, hA8.data(), hA8.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(W8, hW8.data(), hW8.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(wsc, hws.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+  }
   auto make_args = [&](size_t vi) {
     vima::GemmArgs a;
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.bias = bias; a.act = act;
+    if (vars[vi].name == "fp8") { a.A = A8; a.W = W8; a.a8 = 1; a.w8 = 1; a.wscale = wsc; a.ascale = asc; }
     a.tune = &vars[vi].t;
     if (epi == 1) { a.outT = outs[vi]; a.ldT = N; }
     else if (epi == 4) { a.outT = outs[vi]; a.ldT = N; a.resT = outs[vi]; a.ldresT = N; }   // in place, like the model's stream
@@ -174,6 +195,7 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> h0(out_bytes), h1;
   CK(hipMemcpy(h0.data(), outs[0], out_bytes, hipMemcpyDeviceToHost));
   for (size_t vi = 1; vi < vars.size(); ++vi) {
+    if (vars[vi].name == "fp8") continue;        // different operands
     h1.resize(out_bytes);
     CK(hipMemcpy(h1.data(), outs[vi], out_bytes, hipMemcpyDeviceToHost));
     long long diff = 0, first = -1;
@@ -206,6 +228,33 @@ int main(int argc, char** argv) {
         if (err > 0.01 * fabs(acc) + 0.05 * sqrt((double)K) * 0.02) ++bad;
       }
       printf("  [%s] host fp64 check on %d sampled entries: max |err| %.4g (max |ref| %.4g), %d outside bf16 rounding\n", vars[vi].name.c_str(), samples, maxerr, maxref, bad);
+    }
+  }
+  if (any8 && epi == 1 && act == 0 && !bias) {     // host fp64 reference of the fp8 product on sampled entries
+    auto dec = [](uint8_t b) {
+      const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+      const double v = e == 0 ? ldexp((double)m, -9) : ldexp(1.0 + m / 8.0, e - 7);
+      return s ? -v : v;
+    };
+    for (size_t vi = 0; vi < vars.size(); ++vi) {
+      if (vars[vi].name != "fp8") continue;
+      std::vector<uint16_t> ho((size_t)M * N);
+      CK(hipMemcpy(ho.data(), outs[vi], ho.size() * 2, hipMemcpyDeviceToHost));
+      double maxrel = 0; int bad = 0;
+      const int samples = 20000;
+      for (int smp = 0; smp < samples; ++smp) {
+        int m, n;
+        if (smp < 4096) { m = (smp * 37) % M; n = (smp * 101 + (smp >> 6)) % N; }
+        else { m = rnd() % M; n = rnd() % N; }
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += dec(hA8[(size_t)m * K + k]) * dec(hW8[(size_t)n * K + k]);
+        acc *= (double)hws[n] * (double)asc;
+        const double got = bf2f(ho[(size_t)m * N + n]);
+        const double tol = 0.008 * fabs(acc) + 1e-3 * sqrt((double)K) * 240.0 * 240.0 * 0.03 * 0.037;
+        if (fabs(got - acc) > tol) ++bad;
+        if (fabs(acc) > 1.0) maxrel = std::max(maxrel, fabs(got - acc) / fabs(acc));
+      }
+      printf("  [fp8] host fp64 check of the e4m3 product on %d sampled entries: max rel err %.3g (|ref| > 1), %d outside bf16 rounding\n", samples, maxrel, bad);
     }
   }
   for (size_t vi = 0; vi < vars.size(); ++vi) {

@@ -75,7 +75,7 @@ def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
         return {int(m.group(1))} if m else set()
 
     checked = 0
-    for m in re.finditer(r"^(_ZN4vima\S*gemm_persistent_kernelILi\dELi([234])ELb[01]EEE\S*):", src, flags=re.M):
+    for m in re.finditer(r"^(_ZN4vima\S*gemm_(?:persistent|pp)_kernelILi\dELi([234])ELb[01]EEE\S*):", src, flags=re.M):
         body = src[m.end():src.index("s_endpgm", m.end())].split("\n")
         nit = 4 if m.group(2) == "3" else 2        # loads per slab: fp32 residual 4 row groups, gate / bf16 residual 2
         pending, in_asm, loads, since_wait = [], False, 0, 0
@@ -107,6 +107,8 @@ def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
                 for tk in toks[1:]:
                     used |= regs(tk)
                 assert not (used & inflight), (m.group(1), t, sorted(used & inflight)[:4])
-        assert loads in (16, 32), (m.group(1), loads)
+        # 16 (gate / bf16 residual) or 32 (fp32 residual) loads per epilogue; the epilogue is instantiated once per compile-time
+        # (bias, row-scale) combination the kernel can take: 2 copies for these epilogues
+        assert loads in (16, 32, 64), (m.group(1), loads)
         checked += 1
-    assert checked >= 6, checked
+    assert checked >= 9, checked

@@ -167,6 +167,27 @@ __device__ __forceinline__ f32x16_t mma(const Frag<float>& w, const Frag<float>&
   return acc;
 }
 
+// FP8 (OCP e4m3) operands for v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate, K = 64 per instruction): a lane
+// (i = lane & 31, hi = lane >> 5) holds row i's 32 consecutive k of half `hi` = two 16-B chunks of the 128-byte K-tile row
+// (chunks ks*4 + hi*2 + {0,1} for the K = 64 step ks). Both operands are read with the same pattern, so the product does
+// not depend on how the instruction orders k inside a lane's 32 bytes.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+struct Frag8 {
+  i32x8_t v;      // ONE 8-register tuple (the MFMA operand): built from two 16-byte LDS reads without copies
+  __device__ __forceinline__ void load(const char* tile, int r, int ks, int hi) {
+    const int c = ks * 4 + hi * 2;
+    const int sw = swz<128>(r);
+    const i32x4_t a = *reinterpret_cast<const i32x4_t*>(tile + r * 128 + ((c ^ sw) << 4));
+    const i32x4_t b = *reinterpret_cast<const i32x4_t*>(tile + r * 128 + (((c + 1) ^ sw) << 4));
+    v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
+__device__ __forceinline__ f32x16_t mma8(const Frag8& w, const Frag8& a, f32x16_t acc) {
+  // cbsz = blgp = 0: both operands e4m3; scales E8M0 127 = 2^0 (per-tensor / per-channel scales are applied in the epilogue)
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.v, a.v, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 // fused RMSNorm row scale: rsqrt(mean of squares + eps) from the producer's per-64-column partial sums (fixed order)
 __device__ __forceinline__ float rms_row_scale(const float* ssq, int parts, int row, float invk, float eps) {
   const float* q = ssq + (long long)row * parts;
@@ -213,6 +234,8 @@ struct GemmDev {
   int rb, s_hi, s_lo, ro;
   float* ssq_out; const float* rs_ssq; int rs_parts; float rs_invk, rs_eps;
   const float* wscale;   // fp8 weights: per-output-channel dequantisation scale [N], applied to the accumulator column
+  float ascale;          // fp8 ACTIVATIONS (gemm_pp_kernel<.., F8>): the A operand's per-tensor dequantisation scale (x wscale[n])
+  void* out8; int ld8; float out8_inv;   // optional fp8 e4m3 copy of the bf16 output: e4m3(value * out8_inv), saturating at 448
   int mtiles, ntiles;
   int vtotal;   // persistent kernel: number of virtual tile ids = ceil8(mtiles) * ntiles
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
@@ -660,7 +683,10 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
       bcol[ni][j] = make_float4(0.f, 0.f, 0.f, 0.f);
       scol[ni][j] = make_float4(1.f, 1.f, 1.f, 1.f);
       if constexpr (HAS_BIAS) bcol[ni][j] = load4(p.bias + ncol0 + ni * 32 + 4 * j);
-      if (W8) scol[ni][j] = load4(p.wscale + ncol0 + ni * 32 + 4 * j);
+      if (W8) {
+        scol[ni][j] = load4(p.wscale + ncol0 + ni * 32 + 4 * j);
+        scol[ni][j].x *= p.ascale; scol[ni][j].y *= p.ascale; scol[ni][j].z *= p.ascale; scol[ni][j].w *= p.ascale;   // 1 unless the A operand is fp8
+      }
     }
   // the column constants are needed (waited for) HERE, before the per-row prefetch starts: hipcc would otherwise wait for
   // them at their first use with `vmcnt(0)`, i.e. for the prefetched loads issued in between as well
@@ -755,7 +781,17 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
         if constexpr (WIDE8) {
           uint4 o;
           o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
-          *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+          if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+          if ((EPI == 1 || EPI == 4) && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
+            const float q = p.out8_inv;
+            auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); };
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[0].x * q), cl(v[0].y * q), w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[0].z * q), cl(v[0].w * q), w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[1].x * q), cl(v[1].y * q), w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[1].z * q), cl(v[1].w * q), w1, true);
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = make_uint2((unsigned)w0, (unsigned)w1);
+          }
           if (EPI == 4 && ssq_out) {   // RMS partials of the stored (rounded) stream: 4 lanes hold the 32 columns of a slab row
             float sq = sumsq8_bf16(o);
             sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
@@ -1047,12 +1083,15 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 // PFLOP/s against 1.10-1.13 for gemm_persistent_kernel; 131072 x 2304 x 768 bf16-out 980 vs 836 TFLOP/s.
 template <int P> struct PhaseTag { static constexpr int value = P; };
 
-template <int ACT, int EPI>
+// F8: both operands fp8 e4m3 (A [M,K] and W [N,K] BYTES; lda / ldw in elements = bytes), K-tile = 128 elements = the same 128-B
+// rows, 4 v_mfma_scale_f32_32x32x64_f8f6f4 per phase instead of 8 bf16 MFMAs (same 256 matrix-pipe cycles, twice the FLOPs, half
+// the operand bytes per FLOP); the accumulator column is multiplied by wscale[n] * ascale in the epilogue.
+template <int ACT, int EPI, bool F8 = false>
 __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDev p) {
   using T = bf16_t;
   using TL = TileL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RB = 128, BK = 64, MI = 4, NI = 2;
+  constexpr int RB = 128, BK = F8 ? 128 : 64, ES = F8 ? 1 : 2, MI = 4, NI = 2;
   constexpr int SLOT = 16384, EPI_OFF = 8 * SLOT;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1061,7 +1100,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
   const int wm = w >> 2, wn = w & 3;
   const int G = gridDim.x;
   const int nk = p.K / BK;              // even, >= 2 (launcher)
-  const T* A = reinterpret_cast<const T*>(p.A);
+  const char* A = reinterpret_cast<const char*>(p.A);
   const char* W = reinterpret_cast<const char*>(p.W);
 
   // virtual tile id v -> (tm, tn); workgroup b takes v = b, b + G, ... (G % 8 == 0), so v & 7 is its XCD. Within an XCD the
@@ -1100,12 +1139,12 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     for (int i = 0; i < 2; ++i) {
       const int rs = (i * 8 + w) * 8 + (lane >> 3);
       const int c = ((lane & 7) ^ ((rs >> 1) & 7)) * 16;
-      offA[i] = (unsigned)(tm * 256 + (rs >> 6) * 128 + (rs & 63)) * (unsigned)(p.lda * 2) + c;     // A0 rows; A1 = + 64 rows
-      offW[i] = (unsigned)(tn * 256 + (rs >> 5) * 64 + (rs & 31)) * (unsigned)(p.ldw * 2) + c;      // B0 rows; B1 = + 32 rows
+      offA[i] = (unsigned)(tm * 256 + (rs >> 6) * 128 + (rs & 63)) * (unsigned)(p.lda * ES) + c;    // A0 rows; A1 = + 64 rows
+      offW[i] = (unsigned)(tn * 256 + (rs >> 5) * 64 + (rs & 31)) * (unsigned)(p.ldw * ES) + c;     // B0 rows; B1 = + 32 rows
     }
   };
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned stepA1 = 64u * (unsigned)(p.lda * 2), stepB1 = 32u * (unsigned)(p.ldw * 2);
+  const unsigned stepA1 = 64u * (unsigned)(p.lda * ES), stepB1 = 32u * (unsigned)(p.ldw * ES);
   // request half-tile h of the cursor's K-tile into slot(par, h)
   auto stage_half = [&](int par, int h) {
     if (iv < 0) return;
@@ -1179,7 +1218,12 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-    Frag<T> fa[2][4], fb[2][4];     // A sub-tile [mi2][kk] (single buffer), B sub-tiles [b][kk] (both kept)
+    constexpr int KS = F8 ? 2 : 4;  // MFMA k-steps per K-tile
+    typename std::conditional<F8, Frag8, Frag<T>>::type fa[2][KS], fb[2][KS];   // A sub-tile [mi2][kk] (single buffer), B sub-tiles [b][kk] (both kept)
+    auto ldf = [&](auto& f, const char* slot, int row, int kk) {
+      if constexpr (F8) f.load(slot, row, kk, hi);
+      else f.template load<RB>(slot, row, kk, hi);
+    };
     stamp(1);
     // the 128-row halves run one barrier apart (re-joined at the end of the tile so that both run their epilogue together)
     if (wm == 1) __builtin_amdgcn_s_barrier();
@@ -1195,20 +1239,20 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
       // ---- memory segment: fragments of this phase's quadrant, half-tile request(s)
       if constexpr (q == 1) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fb[0][kk].template load<RB>(sl + 0 * SLOT, brow, kk, hi);
+        for (int kk = 0; kk < KS; ++kk) ldf(fb[0][kk], sl + 0 * SLOT, brow, kk);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          fa[0][kk].template load<RB>(sl + 1 * SLOT, arow, kk, hi);
-          fa[1][kk].template load<RB>(sl + 1 * SLOT, arow + 32, kk, hi);
+        for (int kk = 0; kk < KS; ++kk) {
+          ldf(fa[0][kk], sl + 1 * SLOT, arow, kk);
+          ldf(fa[1][kk], sl + 1 * SLOT, arow + 32, kk);
         }
       } else if constexpr (q == 2) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fb[1][kk].template load<RB>(sl + 2 * SLOT, brow, kk, hi);
+        for (int kk = 0; kk < KS; ++kk) ldf(fb[1][kk], sl + 2 * SLOT, brow, kk);
       } else if constexpr (q == 3) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          fa[0][kk].template load<RB>(sl + 3 * SLOT, arow, kk, hi);
-          fa[1][kk].template load<RB>(sl + 3 * SLOT, arow + 32, kk, hi);
+        for (int kk = 0; kk < KS; ++kk) {
+          ldf(fa[0][kk], sl + 3 * SLOT, arow, kk);
+          ldf(fa[1][kk], sl + 3 * SLOT, arow + 32, kk);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1234,9 +1278,17 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
       constexpr int ni = (q == 1 || q == 4) ? 0 : 1;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        acc[mi0][ni] = mma(fb[ni][kk], fa[0][kk], acc[mi0][ni]);
-        acc[mi0 + 1][ni] = mma(fb[ni][kk], fa[1][kk], acc[mi0 + 1][ni]);
+      for (int kk = 0; kk < KS; ++kk) {
+        if constexpr (F8) {
+          acc[mi0][ni] = mma8(fb[ni][kk], fa[0][kk], acc[mi0][ni]);
+          acc[mi0 + 1][ni] = mma8(fb[ni][kk], fa[1][kk], acc[mi0 + 1][ni]);
+          // hipcc sinks these (register-only) instructions out of their phase -- all 32 of an iteration ended up behind phase
+          // 8, with the fragments spilled to scratch; an empty asm that consumes the accumulators pins them here
+          if (kk == KS - 1) asm volatile("" : "+v"(acc[mi0][ni]), "+v"(acc[mi0 + 1][ni]));
+        } else {
+          acc[mi0][ni] = mma(fb[ni][kk], fa[0][kk], acc[mi0][ni]);
+          acc[mi0 + 1][ni] = mma(fb[ni][kk], fa[1][kk], acc[mi0 + 1][ni]);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1260,7 +1312,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     if (wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stamp(2);
-    tile_epilogue_256<ACT, EPI, false>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
+    tile_epilogue_256<ACT, EPI, F8>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
     stamp(3);
     cv = next_valid(cv + G);
     if (cv < 0) break;
@@ -1681,24 +1733,34 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   }
 }
 
-template <int ACT, int EPI>
-int launch_pp_inst(const GemmDev& d, int grid, hipStream_t st) {
+template <int ACT, int EPI, bool F8>
+int launch_pp_inst2(const GemmDev& d, int grid, hipStream_t st) {
   constexpr int SMEM = 8 * 16384 + TileL::NW * 4096;   // eight half-tile slots + epilogue slabs = 160 KiB
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<ACT, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<ACT, EPI, F8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
+  hipLaunchKernelGGL((gemm_pp_kernel<ACT, EPI, F8>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
   return (int)hipGetLastError();
+}
+template <int ACT, int EPI>
+int launch_pp_inst(const GemmDev& d, int grid, hipStream_t st) {
+  if constexpr (EPI == 1 || EPI == 4) {     // the fp8-activation path exists for the bf16-output and bf16-stream epilogues
+    if (d.raster == 8) return launch_pp_inst2<ACT, EPI, true>(d, grid, st);
+  } else {
+    if (d.raster == 8) return (int)hipErrorInvalidValue;
+  }
+  return launch_pp_inst2<ACT, EPI, false>(d, grid, st);
 }
 
 // ping-pong persistent kernel (option gemm_pp): same eligibility as launch_persistent plus an even number of K-tiles and
 // bf16 weights; returns -1 when the problem does not fit it (caller falls back)
 int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
-  if (a.w8 || (a.K / 64) % 2 != 0) return -1;
+  if (a.a8) { if (!a.w8 || a.K % 256 != 0) return -1; }
+  else if (a.w8 || (a.K / 64) % 2 != 0) return -1;
   if (g_num_cu == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -1708,12 +1770,12 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.mtiles = (d.M + TileL::BM - 1) / TileL::BM;
   d.ntiles = (d.N + TileL::BN - 1) / TileL::BN;
   d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
-  d.raster = 0; d.epi_lds = 1;
+  d.raster = a.a8 ? 8 : 0; d.epi_lds = 1;     // raster 8: marker for the fp8-operand instantiation (the kernel ignores `raster`)
   d.ngroup = d.ntiles;
   {   // W panels of one n-group <= `VIMA_GEMM_NGROUP_KB` (default 2560 KiB) so that they stay resident in an XCD's L2
     static int kb = -1;
     if (kb < 0) kb = env_int("VIMA_GEMM_NGROUP_KB", 2560);
-    const long long panel = (long long)TileL::BN * a.K * 2;
+    const long long panel = (long long)TileL::BN * a.K * (a.a8 ? 1 : 2);
     // only for short K: every extra group re-reads the whole A matrix (measured: 131072 x 768 x 3072 in three groups
     // 1167 -> 999 TFLOP/s; 131072 x 3072 x 768 in two groups: same time, W no longer re-streamed from beyond L2)
     if (kb > 0 && a.K <= 1536 && (long long)d.ntiles * panel > (long long)kb * 1024) {
@@ -1883,6 +1945,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
   d.wscale = a.w8 ? a.wscale : nullptr;
+  d.ascale = a.a8 ? a.ascale : 1.0f;
+  d.out8 = a.out8; d.ld8 = a.ld8; d.out8_inv = a.out8_inv;
   if (a.ssq_out && ((!a.out32 && !a.outT) || a.batch > 1 || a.N % 32 != 0)) return (int)hipErrorInvalidValue;
   if (a.rs_ssq && a.rs_parts <= 0) return (int)hipErrorInvalidValue;
   d.mtiles = d.ntiles = 0;
@@ -1896,7 +1960,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.w8 && !v) return (int)hipErrorInvalidValue;   // fp8 weights need the vector epilogue (16-byte aligned outputs)
   d.wide8 = 0;
   if constexpr (sizeof(T) == 2) {
-    d.wide8 = (v && a.outT && !a.out32 && a.N % 8 == 0 && a.ldT % 8 == 0 && a.bsT % 8 == 0 && aligned_to(a.outT, 16) &&
+    d.wide8 = (v && (a.outT || a.out8) && !a.out32 && a.N % 8 == 0 && a.ldT % 8 == 0 && a.bsT % 8 == 0 && aligned_to(a.outT, 16) &&
+               (!a.out8 || (a.ld8 % 8 == 0 && aligned_to(a.out8, 8))) &&
                (!a.mul || (a.ldmul % 8 == 0 && a.bsMul % 8 == 0 && aligned_to(a.mul, 16))) &&
                (!a.resT || (a.ldresT % 8 == 0 && aligned_to(a.resT, 16)))) ? 1 : 0;
     // RMS partials without the fp32 stream exist only in the 8-column layout (statistics of the stored bf16 values)
@@ -1919,15 +1984,18 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
         (long long)a.N * a.ldw * (long long)esw < (1LL << 32)) {
       const int epi_id = a.resT ? 4 : (a.res ? 3 : (a.mul ? 2 : 1));
-      if (gemm_pp(a.tune)) {
+      if (gemm_pp(a.tune) || a.a8) {
         const int e = launch_pp(d, a, st);
-        if (e >= 0) { if (a.kernel_id) *a.kernel_id = 1000 + (a.act + 1) * 10 + epi_id; return e; }
+        if (e >= 0) { if (a.kernel_id) *a.kernel_id = (a.a8 ? 9000 : 1000) + (a.act + 1) * 10 + epi_id; return e; }
       }
+      if (a.a8) return (int)hipErrorInvalidValue;   // fp8 activations exist on the ping-pong kernel only
       const int e = launch_persistent(d, a, st);
       if (e >= 0) { if (a.kernel_id) *a.kernel_id = 2000 + (a.act + 1) * 10 + epi_id; return e; }
     }
+    if (a.a8) return (int)hipErrorInvalidValue;
     if (large) { if (a.kernel_id) *a.kernel_id = 4000 + (a.act + 1) * 10; return launch_tile<T, TileL, true>(d, a, v, st); }
   }
+  if (a.a8) return (int)hipErrorInvalidValue;
 #ifdef VIMA_GEMM_LAB
   return (int)hipErrorInvalidValue;
 #else

@@ -74,6 +74,16 @@ struct GemmArgs {
   // multiplies accumulator column n by wscale[n] before bias / activation. Needs N % 4 == 0, K % 64 == 0, batch 1.
   int w8 = 0;
   const float* wscale = nullptr;
+  // fp8 ACTIVATIONS (precision "fp8"): with a8 = 1, A is [M,K] OCP e4m3 BYTES as well (lda in bytes) with ONE dequantisation scale
+  // `ascale` for the tensor; both operands go to v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_pp_kernel<.., F8>: needs w8, K % 256 == 0 and
+  // the persistent-kernel shape conditions; anything else fails), the accumulator column is multiplied by wscale[n] * ascale.
+  int a8 = 0;
+  float ascale = 1.0f;
+  // optional fp8 copy of the result for an fp8 consumer: out8[r][n] = e4m3(value * out8_inv) (saturating), row stride ld8 BYTES;
+  // bf16-only-output and bf16-stream epilogues of the persistent kernels. With out8 the bf16 output outT may be omitted.
+  void* out8 = nullptr;
+  int ld8 = 0;
+  float out8_inv = 1.0f;
 };
 // returns hipError_t as int; is_bf16 selects the operand type
 int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
