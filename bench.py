@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X (guides/MI355X_MICROARCH.md)
+FP8_PEAK_TFLOPS = 5000.0    # dense fp8 MFMA peak (MX / f8f6f4 K = 64 instructions), same guide
 FP32_PEAK_TFLOPS = 157.3
 
 
@@ -179,7 +180,7 @@ def extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B
     # ---- north_star's other batch sizes, driver-visible in the same run: COLD steps at batch 1 and 32 of
     # the same model / prompt, each with the roofline that binds it (batch 1: the ~676 MB of bf16 weights over HBM;
     # batch 32: bf16 MFMA)
-    WEIGHT_BYTES = {"bf16": 676e6, "fp8w": 370e6, "fp32": 1352e6}[args.precision]          # weights touched once per pass
+    WEIGHT_BYTES = {"bf16": 676e6, "fp8w": 370e6, "fp8": 370e6, "fp32": 1352e6}[args.precision]          # weights touched once per pass
     for b2 in (1, 32):
         if b2 >= B:
             continue
@@ -223,7 +224,7 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--qv", type=int, default=4, help="objects per view (Q = 2*qv object tokens per observation)")
     ap.add_argument("--words", type=int, default=8, help="words per prompt segment (a segment = words + 1 image)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8w"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8w", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the warm / incremental / batch-1 / batch-32 extras (profiler runs: "
                     "every kernel launch in the trace then belongs to the headline workload)")
@@ -358,7 +359,9 @@ def main():
     HBM_PEAK_GBS = 8000.0
     g0, g3 = prof["gemm"], prof["gemm_residual"]
 
-    def klass(d, name):
+    def klass(d, name, peak=peak):
+        if name.endswith(", true>"):
+            peak = FP8_PEAK_TFLOPS           # fp8 e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4: priced against the 5 PF dense fp8 peak
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         inten = d["flops"] / d["bytes"] if d["bytes"] > 0 else 0.0
@@ -386,7 +389,7 @@ def main():
         "gemm_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0,
                              "algorithmic_mb_per_launch": round(v["bytes"] / max(v["launches"], 1) / 1e6, 1)}
-                         for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                         for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["ms"])[:10]},
         "gemm_classes": [k_plain, k_res],
         "all_gemm": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
                      "launches_per_step": g0["launches"] + g3["launches"], "ms_per_step": round(gemm_ms, 3)},
@@ -410,7 +413,7 @@ def main():
         if not (ms == ms and ms > 0):
             return None
         kv_bytes = cfg.xf_n_layers * B * args.prompt_len * 2 * cfg.embed_dim * 2.0
-        w_bytes = {"bf16": 676e6, "fp8w": 370e6, "fp32": 1352e6}[args.precision] * 0.45      # decoder + obs ViT + heads (no T5)
+        w_bytes = {"bf16": 676e6, "fp8w": 370e6, "fp8": 370e6, "fp32": 1352e6}[args.precision] * 0.45      # decoder + obs ViT + heads (no T5)
         t_mfma, t_hbm = flops / (peak * 1e12) * 1e3, (kv_bytes + w_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
         return {"bound": "hbm" if t_hbm > t_mfma else "mfma", "mfma_ms": round(t_mfma, 4), "hbm_ms": round(t_hbm, 4),
                 "roofline_ms": round(max(t_mfma, t_hbm), 4), "frac": round(max(t_mfma, t_hbm) / ms, 4),

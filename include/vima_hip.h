@@ -28,7 +28,11 @@ typedef void* vima_stream_t; /* hipStream_t */
  * layers are stored as OCP FP8 E4M3 with one fp32 scale per output channel (half the weight bytes in HBM / L2 / LDS);
  * the GEMM kernels widen the fp8 fragments to bf16 in registers. Logit error vs the fp32 reference is a few 1e-3 (weights
  * only carry 3 mantissa bits) -- measured and reported by the tests, not covered by the 1e-3 gate of the bf16 mode. */
-enum { VIMA_PRECISION_FP32 = 0, VIMA_PRECISION_BF16 = 1, VIMA_PRECISION_FP8W = 2 };
+enum { VIMA_PRECISION_FP32 = 0, VIMA_PRECISION_BF16 = 1, VIMA_PRECISION_FP8W = 2, VIMA_PRECISION_FP8 = 3 };
+/* FP8W: bf16 activations and matrix instruction, OCP e4m3 weights (+ one fp32 scale per output channel) for the large Linear layers.
+ * FP8 : FP8W plus e4m3 ACTIVATIONS into the large GEMMs of the T5 stack, the ViT and the decoder's prompt K/V projection (one static
+ *       scale per layer and site, calibrated by the handle's first pass through each, which runs the FP8W kernels) on
+ *       v_mfma_scale_f32_32x32x64_f8f6f4 -- BASELINE.json configs[4]. Shapes the fp8 kernel does not cover keep bf16 activations. */
 
 /* Which policy class of vima/policy/ the handle implements. VIMA is the hot path (vima_policy.py); the other three are the
  * reference's baseline policies, which consume whole 64x128 RGB frames instead of object crops:
@@ -205,6 +209,11 @@ int vima_op_layernorm(VimaHandle* h, const float* x, const float* gamma, const f
 int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float* v, const uint8_t* kmask,
                       const float* relbias, int B, int H, int Lq, int Lk, int D, float scale, int mode, int impl,
                       float* out, vima_stream_t stream);
+/* precision FP8: the calibrated activation scales (dequantisation scale = max |x| / 448) of group 0 the T5 stack [12 layers][4 sites:
+ * stream before qkv, attention context, stream before wi, ReLU hidden], 1 the ViT [4 blocks][4 sites: ln_1 output, attention output,
+ * ln_2 output, QuickGELU hidden], 2 the decoder's prompt K/V projection [1]; returns their number (0 before that group's calibrating
+ * pass, < 0 on error). Option "fp8_recalibrate" makes the next pass of every group measure them again. */
+int vima_fp8_act_scales(VimaHandle* h, int group, float* out, int max_n);
 /* host-only: the fp32 -> OCP FP8 E4M3 (round to nearest even, saturating at 448) encoder the FP8W weight packing uses */
 void vima_fp8_e4m3_encode(const float* src, uint8_t* dst, int64_t n);
 /* host-only: HF T5 bidirectional relative-position bucket (32 buckets, max distance 128) of (key_pos - query_pos) */

@@ -75,3 +75,56 @@ def fake_quant_state_dict(sd: dict, t5_fused_rms: bool = True) -> dict:
         else:
             out[k] = _q_rows(w)
     return out
+
+
+# ---- precision "fp8": fp8 e4m3 ACTIVATIONS into the T5 stack's four GEMMs per layer, one static dequantisation scale per
+# (layer, site) -- sites: 0 stream before qkv, 1 attention context, 2 stream before wi, 3 ReLU hidden (vima_api.hip t5_layer_fp8).
+def fq_act(t: torch.Tensor, scale: float) -> torch.Tensor:
+    """dequant(e4m3(t / scale)), saturating at 448, round to nearest even: what the fp8 GEMM multiplies with."""
+    return (t / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+
+
+def make_fp8_act_oracle(sd: dict, act_scales: torch.Tensor, vit_scales: torch.Tensor | None = None, kv_scale: float | None = None, **ctor):
+    """OraclePolicy on fake-quantised weights whose T5 stack also fake-quantises the four GEMM inputs of every layer with the
+    given scales [n_layers, 4]. The RMSNorm statistics come from the UNquantised stream (the library takes them from the bf16
+    stream's partial sums, vima_api.hip t5_layer_fp8), only the GEMM operand is quantised. `vit_scales` [4, 4]: the same for the
+    ViT while the attribute `fq_vit` is True (the library quantises only chunks of >= 13824 crops: the prompt's, not one
+    observation's); `kv_scale`: the prompt entering the decoder's key_value projections."""
+    from .vima_oracle import OraclePolicy, FMIN, _lin, t5_relative_position_bucket
+
+    class _Fp8ActOracle(OraclePolicy):
+        fq_vit = False
+
+        def _fq(self, group, idx, site, t):
+            if group == "vit" and vit_scales is not None and self.fq_vit:
+                return fq_act(t, float(vit_scales[idx, site]))
+            if group == "kv" and kv_scale is not None:
+                return fq_act(t, float(kv_scale))
+            return t
+
+        def _t5(self, x, mask_f):
+            sdd, p = self.sd, "t5_prompt_encoder.t5.encoder."
+            B, L, D = x.shape
+            H, dk = 12, 64
+            ext = (1.0 - mask_f[:, None, None, :]) * FMIN
+            pos = torch.arange(L, device=x.device)
+            bucket = t5_relative_position_bucket(pos[None, :] - pos[:, None])
+            rb = sdd[p + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"][bucket]
+            position_bias = rb.permute(2, 0, 1).unsqueeze(0) + ext
+            for l in range(act_scales.shape[0]):
+                s = [float(v) for v in act_scales[l]]
+                a = f"{p}block.{l}.layer.0."
+                h = sdd[a + "layer_norm.weight"] * (fq_act(x, s[0]) * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6))
+                q = _lin(h, sdd[a + "SelfAttention.q.weight"]).view(B, L, H, dk).transpose(1, 2)
+                k = _lin(h, sdd[a + "SelfAttention.k.weight"]).view(B, L, H, dk).transpose(1, 2)
+                v = _lin(h, sdd[a + "SelfAttention.v.weight"]).view(B, L, H, dk).transpose(1, 2)
+                w = torch.softmax((q @ k.transpose(3, 2) + position_bias).float(), dim=-1)
+                o = (w @ v).transpose(1, 2).reshape(B, L, H * dk)
+                x = x + _lin(fq_act(o, s[1]), sdd[a + "SelfAttention.o.weight"])
+                f = f"{p}block.{l}.layer.1."
+                h = sdd[f + "layer_norm.weight"] * (fq_act(x, s[2]) * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6))
+                h = torch.relu(_lin(h, sdd[f + "DenseReluDense.wi.weight"]))
+                x = x + _lin(fq_act(h, s[3]), sdd[f + "DenseReluDense.wo.weight"])
+            return self._rms(x, sdd[p + "final_layer_norm.weight"])
+
+    return _Fp8ActOracle(fake_quant_state_dict(sd, t5_fused_rms=True), **ctor)

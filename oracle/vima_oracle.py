@@ -80,6 +80,12 @@ class OraclePolicy:
             raise ValueError("embed_dim must be divisible by the head counts")  # components.py:120-123
 
     # ------------------------------------------------------------------ object encoder
+    def _fq(self, group, idx, site, t):
+        """Hook for activation fake-quantisation (oracle/fp8_quant.py overrides it): group "vit" (block idx; sites 0 ln_1 output,
+        1 attention output, 2 ln_2 output, 3 QuickGELU hidden) or "kv" (the prompt entering the cross-attention key_value
+        projection). Identity here."""
+        return t
+
     def _vit(self, img_u8):
         """ViTEncoder.forward (vit.py:36-46) + basic_image_tensor_preprocess (preprocess.py:9-43)
         + VisionTransformer.forward (vit.py:171-191) + ResidualAttentionBlock (vit.py:199-236)."""
@@ -102,18 +108,18 @@ class OraclePolicy:
         n_blocks = 1 + max(int(k[len(p + "blocks."):].split(".")[0]) for k in sd if k.startswith(p + "blocks."))
         for j in range(n_blocks):
             b = f"{p}blocks.{j}."
-            h = F.layer_norm(x, (W,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
+            h = self._fq("vit", j, 0, F.layer_norm(x, (W,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5))
             qkv = _lin(h, sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"])  # nn.MultiheadAttention
             q, k, v = qkv.split(W, dim=-1)
             q = q.view(M, -1, heads, d).transpose(1, 2)
             k = k.view(M, -1, heads, d).transpose(1, 2)
             v = v.view(M, -1, heads, d).transpose(1, 2)
             att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v
-            att = att.transpose(1, 2).reshape(M, -1, W)
+            att = self._fq("vit", j, 1, att.transpose(1, 2).reshape(M, -1, W))
             x = x + _lin(att, sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"])
-            h = F.layer_norm(x, (W,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
+            h = self._fq("vit", j, 2, F.layer_norm(x, (W,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5))
             h = _lin(h, sd[b + "mlp.c_fc.weight"], sd[b + "mlp.c_fc.bias"])
-            h = h * torch.sigmoid(1.702 * h)                                   # QuickGELU vit.py:194-196
+            h = self._fq("vit", j, 3, h * torch.sigmoid(1.702 * h))            # QuickGELU vit.py:194-196
             x = x + _lin(h, sd[b + "mlp.c_proj.weight"], sd[b + "mlp.c_proj.bias"])
         x = F.layer_norm(x[:, 0, :], (W,), sd[p + "ln_post.weight"], sd[p + "ln_post.bias"], 1e-5)
         x = x @ sd[p + "projection"]                                           # vit.py:188-189
@@ -283,7 +289,7 @@ class OraclePolicy:
         Lp = kv.shape[1]
         qn = F.layer_norm(q, (E,), sd[p + "layernorm.weight"], sd[p + "layernorm.bias"], 1e-5)
         qs = _lin(qn, sd[p + "query.weight"]).view(B, Lq, H, d).transpose(1, 2)
-        k, v = _lin(kv, sd[p + "key_value.weight"]).chunk(2, dim=-1)
+        k, v = _lin(self._fq("kv", 0, 0, kv), sd[p + "key_value.weight"]).chunk(2, dim=-1)
         k = k.view(B, Lp, H, d).transpose(1, 2)
         v = v.view(B, Lp, H, d).transpose(1, 2)
         s = qs @ k.transpose(-1, -2) / math.sqrt(d)

@@ -22,7 +22,7 @@ class VimaConfig(ctypes.Structure):
                                      "xattn_n_positions", "n_positions", "precision", "policy_kind")]
 
 
-PRECISION = {"fp32": 0, "bf16": 1, "fp8w": 2}
+PRECISION = {"fp32": 0, "bf16": 1, "fp8w": 2, "fp8": 3}
 POLICY_KIND = {"vima": 0, "gpt": 1, "gato": 2, "flamingo": 3}   # VIMA_POLICY_* (include/vima_hip.h)
 
 # exported symbol -> (restype, argtypes); must list every function declared in include/vima_hip.h
@@ -66,6 +66,7 @@ PROTOTYPES = {
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "vima_prof_read_gemm_kernels": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
                                                    ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "vima_fp8_act_scales": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "vima_workspace_bytes": (c_i64, [vp]),
     "vima_graph_stats": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "vima_crop_objects": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,

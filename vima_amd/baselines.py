@@ -25,8 +25,8 @@ class _BaselinePolicy(VIMAPolicy):
 
     def __init__(self, *, embed_dim, n_layer, n_head, xattn_n_heads=None, vocab_size=40478, n_positions=512,
                  precision="bf16", device=None):
-        if precision == "fp8w":
-            raise ValueError("precision 'fp8w' is validated for VIMAPolicy only; the baseline policies run in 'bf16' or 'fp32'")
+        if precision in ("fp8w", "fp8"):
+            raise ValueError(f"precision '{precision}' is validated for VIMAPolicy only; the baseline policies run in 'bf16' or 'fp32'")
         super().__init__(embed_dim=embed_dim, xf_n_layers=n_layer, sattn_n_heads=n_head,
                          xattn_n_heads=xattn_n_heads or n_head, xattn_n_positions=256, n_positions=n_positions,
                          precision=precision, device=device)

@@ -21,7 +21,7 @@ namespace {
 // =============================================================================================== ViT (S <= 8, D = 32)
 template <typename T>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, long long total,
-                                                        int S, int W, int heads) {
+                                                        int S, int W, int heads, uint8_t* out8 = nullptr, float inv8 = 1.0f) {
   constexpr int D = 32;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -77,6 +77,15 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
       }
     }
   }
+  if (out8) {   // precision "fp8": the consumer GEMM (out_proj) takes e4m3 activations
+    uint32_t w[8];
+#pragma unroll
+    for (int c = 0; c < D; c += 4) w[c >> 2] = pack4_fp8(make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]), inv8);
+    uint4* o8 = reinterpret_cast<uint4*>(out8 + mi * W + h * D);
+    o8[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    o8[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    return;
+  }
   T* op = out + mi * W + h * D;
 #pragma unroll
   for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
@@ -86,7 +95,8 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
 // q: T [M, W] (cls rows), kv: T [M*S, 2W] (K | V of every token) -> out T [M, W]. One thread per (crop, head).
 template <typename T>
 __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__ qb, const T* __restrict__ kv,
-                                                            T* __restrict__ out, long long total, int S, int W, int heads) {
+                                                            T* __restrict__ out, long long total, int S, int W, int heads,
+                                                            uint8_t* out8 = nullptr, float inv8 = 1.0f) {
   constexpr int D = 32;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -140,6 +150,15 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
         o[c + 2] = fmaf(pj, v.z, o[c + 2]); o[c + 3] = fmaf(pj, v.w, o[c + 3]);
       }
     }
+  }
+  if (out8) {
+    uint32_t w[8];
+#pragma unroll
+    for (int c = 0; c < D; c += 4) w[c >> 2] = pack4_fp8(make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]), inv8);
+    uint4* o8 = reinterpret_cast<uint4*>(out8 + m * W + h * D);
+    o8[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    o8[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    return;
   }
   T* op = out + m * W + h * D;
 #pragma unroll
@@ -925,22 +944,23 @@ inline AttnDev to_dev(const AttnArgs& a) {
 
 }  // namespace
 
-int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st) {
+int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st, void* out8, float inv8) {
   if (M <= 0) return 0;
-  if (S > 8 || W / heads != 32 || W % heads) return (int)hipErrorInvalidValue;
+  if (S > 8 || W / heads != 32 || W % heads || (out8 && !is_bf16)) return (int)hipErrorInvalidValue;
   const long long total = (long long)M * S * heads;
   const unsigned g = (unsigned)((total + 255) / 256);
-  if (is_bf16) hipLaunchKernelGGL(vit_attn_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, total, S, W, heads);
+  if (is_bf16) hipLaunchKernelGGL(vit_attn_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, total, S, W, heads, (uint8_t*)out8, inv8);
   else hipLaunchKernelGGL(vit_attn_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)qkv, (float*)out, total, S, W, heads);
   return (int)hipGetLastError();
 }
 
-int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st) {
+int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st, void* out8,
+                        float inv8) {
   if (M <= 0) return 0;
-  if (S > 8 || W / heads != 32 || W % heads) return (int)hipErrorInvalidValue;
+  if (S > 8 || W / heads != 32 || W % heads || (out8 && !is_bf16)) return (int)hipErrorInvalidValue;
   const long long total = (long long)M * heads;
   const unsigned g = (unsigned)((total + 255) / 256);
-  if (is_bf16) hipLaunchKernelGGL(vit_attn_cls_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, total, S, W, heads);
+  if (is_bf16) hipLaunchKernelGGL(vit_attn_cls_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, total, S, W, heads, (uint8_t*)out8, inv8);
   else hipLaunchKernelGGL(vit_attn_cls_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)out, total, S, W, heads);
   return (int)hipGetLastError();
 }

@@ -58,6 +58,14 @@ __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// 4 floats -> 4 OCP e4m3 bytes of e4m3(v * inv), saturating at 448, round to nearest even (byte 0 = v.x)
+__device__ __forceinline__ uint32_t pack4_fp8(float4 v, float inv) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.x * inv, -448.0f, 448.0f), __builtin_amdgcn_fmed3f(v.y * inv, -448.0f, 448.0f), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.z * inv, -448.0f, 448.0f), __builtin_amdgcn_fmed3f(v.w * inv, -448.0f, 448.0f), w, true);
+  return (uint32_t)w;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

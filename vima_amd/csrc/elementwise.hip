@@ -15,7 +15,8 @@ constexpr int LN_MAXV = 4;  // float4 per lane -> E <= 1024
 template <typename T, typename TIN = float>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ in, long long ldin,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, int rms, int rows, int E, float* out32, T* outT) {
+                                                         float eps, int rms, int rows, int E, float* out32, T* outT,
+                                                         uint8_t* out8 = nullptr, float inv8 = 1.0f) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
       }
       if (out32) store4(out32 + (long long)row * E + c * 4, o);
       if (outT) store4(outT + (long long)row * E + c * 4, o);
+      if (out8) *reinterpret_cast<uint32_t*>(out8 + (long long)row * E + c * 4) = pack4_fp8(o, inv8);   // precision "fp8": e4m3 copy
     }
   }
 }
@@ -404,9 +406,67 @@ __global__ __launch_bounds__(256) void rms_stats_kernel(const float* __restrict_
   if (lane == 0) ssq[row] = q;
 }
 
+// ---- fp8 activations (precision "fp8"): per-tensor static scales. quant: out8 = e4m3(in * inv), saturating at 448 (the
+// conversion the GEMM epilogue's fp8 emission uses); amax: slot = max(slot, max |in|) (non-negative floats order like their
+// bit patterns, so one unsigned atomicMax per wave)
+__global__ __launch_bounds__(256) void quant_fp8_kernel(const bf16_t* __restrict__ in, long long ldin, long long rows, int cols, float inv,
+                                                        uint8_t* __restrict__ out, long long ldo) {
+  const int cpr = cols >> 3;                                   // 8 elements per thread
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long long r = i / cpr;
+  const int c = (int)(i - r * cpr) * 8;
+  const uint4 u = *reinterpret_cast<const uint4*>(in + r * ldin + c);
+  auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); };
+  auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+  auto hi = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(lo(u.x) * inv), cl(hi(u.x) * inv), w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(lo(u.y) * inv), cl(hi(u.y) * inv), w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(lo(u.z) * inv), cl(hi(u.z) * inv), w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(lo(u.w) * inv), cl(hi(u.w) * inv), w1, true);
+  *reinterpret_cast<uint2*>(out + r * ldo + c) = make_uint2((unsigned)w0, (unsigned)w1);
+}
+
+__global__ __launch_bounds__(256) void amax_kernel(const bf16_t* __restrict__ in, long long ldin, long long rows, int cols, unsigned* slot) {
+  const int cpr = cols >> 3;
+  const long long total = rows * cpr;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    const uint4 u = *reinterpret_cast<const uint4*>(in + r * ldin + c);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m = fmaxf(m, fabsf(__uint_as_float(w[j] << 16)));
+      m = fmaxf(m, fabsf(__uint_as_float(w[j] & 0xffff0000u)));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m == m) atomicMax(slot, __float_as_uint(m));
+}
+
 inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
+
+int launch_quant_fp8(const void* inT, long long ldin, long long rows, int cols, float inv, void* out8, long long ldo, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (cols % 8 || ldin % 8 || ldo % 8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(quant_fp8_kernel, dim3(nblk(rows * (cols >> 3), 256)), dim3(256), 0, st, (const bf16_t*)inT, ldin, rows, cols, inv,
+                     (uint8_t*)out8, ldo);
+  return (int)hipGetLastError();
+}
+
+int launch_amax(const void* inT, long long ldin, long long rows, int cols, float* slot, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (cols % 8 || ldin % 8) return (int)hipErrorInvalidValue;
+  unsigned g = nblk(rows * (cols >> 3), 256 * 8);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(amax_kernel, dim3(g), dim3(256), 0, st, (const bf16_t*)inT, ldin, rows, cols, reinterpret_cast<unsigned*>(slot));
+  return (int)hipGetLastError();
+}
 
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st) {
@@ -422,12 +482,15 @@ int launch_layernorm(const float* in, long long ldin, const float* gamma, const 
 }
 
 int launch_layernorm_T(const void* inT, long long ldin, const float* gamma, const float* beta, float eps, int rms, int rows,
-                       int E, float* out32, void* outT, bool is_bf16, hipStream_t st) {
-  if (!is_bf16) return launch_layernorm((const float*)inT, ldin, gamma, beta, eps, rms, rows, E, out32, outT, false, st);
+                       int E, float* out32, void* outT, bool is_bf16, hipStream_t st, void* out8, float inv8) {
+  if (!is_bf16) {
+    if (out8) return (int)hipErrorInvalidValue;
+    return launch_layernorm((const float*)inT, ldin, gamma, beta, eps, rms, rows, E, out32, outT, false, st);
+  }
   if (rows <= 0) return 0;
   if (E % 4 != 0 || E > 64 * 4 * LN_MAXV || ldin % 4 != 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const bf16_t*)inT, ldin, gamma, beta,
-                     eps, rms, rows, E, out32, (bf16_t*)outT);
+                     eps, rms, rows, E, out32, (bf16_t*)outT, (uint8_t*)out8, inv8);
   return (int)hipGetLastError();
 }
 

@@ -99,9 +99,14 @@ int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
 // the same with the input rows in the operand type T (residual stream carried in T)
+// out8 (bf16 mode only): additionally (or, with outT == nullptr, only) the fp8 e4m3 copy e4m3(result * inv8), row stride E bytes
 int launch_layernorm_T(const void* inT, long long ldin, const float* gamma, const float* beta, float eps, int rms, int rows,
-                       int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
+                       int E, float* out32, void* outT, bool is_bf16, hipStream_t st, void* out8 = nullptr, float inv8 = 1.0f);
 int launch_cast(const float* in, void* outT, long long n, bool is_bf16, hipStream_t st);
+// fp8 activations (precision "fp8"): out8[r][c] = e4m3(in[r][c] * inv) of bf16 rows (saturating at 448; cols, strides % 8 == 0);
+// *slot = max(*slot, max |in|) (slot holds a non-negative float, zero it before the first call)
+int launch_quant_fp8(const void* inT, long long ldin, long long rows, int cols, float inv, void* out8, long long ldo, hipStream_t st);
+int launch_amax(const void* inT, long long ldin, long long rows, int cols, float* slot, hipStream_t st);
 // operand-type copy of fp32 rows + their sum of squares (entry point of the fused-RMSNorm chain): outT[r][:] = in[r][:],
 // ssq[r] = sum in[r][:]^2
 int launch_rms_stats(const float* in, int rows, int E, void* outT, float* ssq, bool is_bf16, hipStream_t st);
@@ -155,9 +160,11 @@ int launch_fill_u8(uint8_t* p, long long n, uint8_t v, hipStream_t st);
 
 // ---------------------------------------------------------------- attention
 // ViT: 5-token (S <= 8) multi-head attention on packed qkv T [M*S, 3*W] -> T [M*S, W]; head dim 32
-int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st);
+// out8 (bf16 mode): write the result as fp8 e4m3(value * inv8) [M*S, W] bytes INSTEAD of the operand-type output
+int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st, void* out8 = nullptr, float inv8 = 1.0f);
 // last ViT block: cls-token query only. q T [M, W], kv T [M*S, 2W] -> out T [M, W]
-int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st);
+int launch_vit_attn_cls(const void* q, const void* kv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st,
+                        void* out8 = nullptr, float inv8 = 1.0f);
 
 enum AttnMode : int { ATTN_T5 = 0, ATTN_CROSS = 1, ATTN_CAUSAL = 2 };
 struct AttnArgs {

@@ -155,7 +155,20 @@ struct VimaHandle {
   VimaConfig cfg;
   int device = 0;
   bool bf16 = true;
-  bool w8 = false;          // precision "fp8w": bf16 activations / MFMA, fp8 e4m3 weights for the large Linear layers
+  bool w8 = false;          // precision "fp8w" / "fp8": fp8 e4m3 weights (+ per-output-channel scales) for the large Linear layers
+  // precision "fp8": the T5 stack's GEMMs ALSO take fp8 e4m3 activations with one static scale per (layer, site) and run on
+  // v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_pp_kernel<.., F8>). Scales are calibrated by the first T5 pass of the handle (which runs
+  // the fp8w kernels and records max |x| per site); sites per layer: 0 stream before qkv, 1 attention context, 2 stream before
+  // wi, 3 ReLU hidden.
+  bool a8 = false;
+  // the same for the ViT (chunks of >= 13824 crops: sites per block 0 ln_1 output, 1 attention output, 2 ln_2 output, 3 QuickGELU
+  // hidden) and for the decoder's prompt K/V projection (one site: prompt + position embedding)
+  bool vit8_ready = false, kv8_ready = false;
+  std::vector<float> vit8_scale, kv8_scale;
+  float *vit8_amax = nullptr, *kv8_amax = nullptr;
+  bool fp8_ready = false;
+  std::vector<float> fp8_scale;      // [kT5Layers * 4] dequantisation scales (amax / 448)
+  float* fp8_amax = nullptr;         // device, [kT5Layers * 4]
   bool finalized = false;
   int attn_impl = 1;
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
@@ -687,10 +700,10 @@ struct Run {
     return err;
   }
   int lnT(const void* inT, long long ldin, const float* g, const float* b, float eps, int rms, int rows, int E, float* out32,
-          void* outT) {
+          void* outT, void* out8 = nullptr, float inv8 = 1.0f) {
     if (err) return err;
     prof_begin(2, 0);
-    int e = launch_layernorm_T(inT, ldin, g, b, eps, rms, rows, E, out32, outT, h->bf16, st);
+    int e = launch_layernorm_T(inT, ldin, g, b, eps, rms, rows, E, out32, outT, h->bf16, st, out8, inv8);
     prof_end();
     if (e) err = fail(std::string("layernorm launch failed: ") + hipGetErrorString((hipError_t)e), e);
     return err;
@@ -734,10 +747,14 @@ int join_aux(Run& R) {
   return 0;
 }
 
-struct VitBuf { void* P; float* pre; float* x; void *hT, *qkv, *att, *u, *y; void *xT, *cT; };   // xT / cT: stream in the operand type
+struct VitBuf { void* P; float* pre; float* x; void *hT, *qkv, *att, *u, *y; void *xT, *cT; void *h8 = nullptr, *att8 = nullptr, *u8 = nullptr; };   // xT / cT: stream in the operand type; *8: fp8 operands (precision "fp8")
 
 // ViT (vit.py:171-191) on internal crop rows [r0, r0+mc) -> cat[r0.., 0:768]
-void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int mc, const VitBuf& b, void* cat) {
+// f8mode 0: operand-type activations; 1: the same + max |x| of every fp8 site into amax[block * 4 + site] (calibration);
+// 2: fp8 e4m3 activations into the 16 large GEMMs with the scales sc[block * 4 + site] (needs stream_T and a chunk whose GEMM
+// shapes fit gemm_pp_kernel<.., F8>: the caller checks)
+void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int mc, const VitBuf& b, void* cat, int f8mode = 0,
+               float* amax = nullptr, const float* sc = nullptr) {
   VimaHandle* h = R.h;
   // patchify, honouring the view boundary inside the chunk
   for (int vi = 0; vi < 2; ++vi) {
@@ -767,27 +784,81 @@ void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int 
   auto norm = [&](const float* in32, const void* inT, long long ldin, const float* g, const float* bb, int M, void* out) {
     return sT ? R.lnT(inT, ldin, g, bb, 1e-5f, 0, M, kVitW, nullptr, out) : R.ln(in32, ldin, g, bb, 1e-5f, 0, M, kVitW, nullptr, out);
   };
+  auto cal = [&](int j, int site, const void* t, long long nrows, int cols) {
+    if (f8mode == 1) OTHER(R, launch_amax(t, cols, nrows, cols, amax + j * 4 + site, R.st), "amax");
+  };
+  // fp8 forms: LayerNorm of the bf16 stream straight to e4m3, GEMM with e4m3 A (and fp8 weights) -> bf16 / stream / e4m3 output
+  auto norm8 = [&](const void* inT, long long ldin, const float* g, const float* bb, int M, float s) {
+    return R.lnT(inT, ldin, g, bb, 1e-5f, 0, M, kVitW, nullptr, nullptr, b.h8, 1.0f / s);
+  };
+  auto gemm8 = [&](const void* A8, int lda, float ascale, const Lin& L, int row0, int N, int M, int act, const void* resT, int ldresT, void* outT,
+                   int ldT, void* out8, int ld8, float oscale) {
+    GemmArgs g;
+    g.A = A8; g.lda = lda; g.a8 = 1; g.ascale = ascale; R.setW(g, L, row0); g.M = M; g.N = N; g.K = L.K; g.bias = L.b ? L.b + row0 : nullptr;
+    g.act = act; g.resT = resT; g.ldresT = ldresT; g.outT = outT; g.ldT = ldT;
+    if (out8) { g.out8 = out8; g.ld8 = ld8; g.out8_inv = 1.0f / oscale; }
+    return R.gemm(g);
+  };
+  if (f8mode == 2) {
+    for (int j = 0; j < kVitLayers - (prune ? 1 : 0); ++j) {
+      auto& B = h->vit.blk[j];
+      const float* s = sc + j * 4;
+      norm8(b.xT, kVitW, B.ln1g, B.ln1b, rows, s[0]);
+      gemm8(b.h8, kVitW, s[0], B.in_proj, 0, 3 * kVitW, rows, ACT_NONE, nullptr, 0, b.qkv, 3 * kVitW, nullptr, 0, 0.f);
+      R.prof_begin(1, 4.0 * mc * kVitHeads * 25.0 * 32);
+      int e = launch_vit_attn(b.qkv, nullptr, mc, 5, kVitW, kVitHeads, true, R.st, b.att8, 1.0f / s[1]);
+      R.prof_end();
+      R.other(e, "vit_attn");
+      gemm8(b.att8, kVitW, s[1], B.out_proj, 0, kVitW, rows, ACT_NONE, b.xT, kVitW, b.xT, kVitW, nullptr, 0, 0.f);
+      norm8(b.xT, kVitW, B.ln2g, B.ln2b, rows, s[2]);
+      gemm8(b.h8, kVitW, s[2], B.fc, 0, 4 * kVitW, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 4 * kVitW, b.u8, 4 * kVitW, s[3]);
+      gemm8(b.u8, 4 * kVitW, s[3], B.proj, 0, kVitW, rows, ACT_NONE, b.xT, kVitW, b.xT, kVitW, nullptr, 0, 0.f);
+    }
+  } else
   for (int j = 0; j < kVitLayers - (prune ? 1 : 0); ++j) {
     auto& B = h->vit.blk[j];
     norm(x, b.xT, kVitW, B.ln1g, B.ln1b, rows, b.hT);
+    cal(j, 0, b.hT, rows, kVitW);
     R.linear(b.hT, kVitW, B.in_proj, rows, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, b.qkv, 3 * kVitW);
     R.prof_begin(1, 4.0 * mc * kVitHeads * 25.0 * 32);
     int e = launch_vit_attn(b.qkv, b.att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
     R.prof_end();
     R.other(e, "vit_attn");
+    cal(j, 1, b.att, rows, kVitW);
     residual(b.att, kVitW, B.out_proj, rows, x, kVitW, x, b.xT, kVitW, b.xT, kVitW);
     norm(x, b.xT, kVitW, B.ln2g, B.ln2b, rows, b.hT);
+    cal(j, 2, b.hT, rows, kVitW);
     R.linear(b.hT, kVitW, B.fc, rows, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, 4 * kVitW);
+    cal(j, 3, b.u, rows, 4 * kVitW);
     residual(b.u, 4 * kVitW, B.proj, rows, x, kVitW, x, b.xT, kVitW, b.xT, kVitW);
   }
   const float* xpost = x;        // rows ln_post reads (cls token of every crop)
   const void* xpostT = b.xT;
   long long ld_post = 5 * kVitW;
-  if (prune) {
+  if (prune && f8mode == 2) {   // the cls-only last block with fp8 activations
+    auto& B = h->vit.blk[kVitLayers - 1];
+    const float* s = sc + (kVitLayers - 1) * 4;
+    norm8(b.xT, kVitW, B.ln1g, B.ln1b, rows, s[0]);
+    gemm8(b.h8, kVitW, s[0], B.in_proj, kVitW, 2 * kVitW, rows, ACT_NONE, nullptr, 0, b.qkv, 2 * kVitW, nullptr, 0, 0.f);      // K, V of all 5 tokens
+    gemm8(b.h8, 5 * kVitW, s[0], B.in_proj, 0, kVitW, mc, ACT_NONE, nullptr, 0, b.y, kVitW, nullptr, 0, 0.f);                   // Q of the cls token
+    R.prof_begin(1, 4.0 * mc * kVitHeads * 5.0 * 32);
+    int e = launch_vit_attn_cls(b.y, b.qkv, nullptr, mc, 5, kVitW, kVitHeads, true, R.st, b.att8, 1.0f / s[1]);
+    R.prof_end();
+    R.other(e, "vit_attn_cls");
+    gemm8(b.att8, kVitW, s[1], B.out_proj, 0, kVitW, mc, ACT_NONE, b.xT, 5 * kVitW, b.cT, kVitW, nullptr, 0, 0.f);             // xc = x_cls + attn
+    norm8(b.cT, kVitW, B.ln2g, B.ln2b, mc, s[2]);
+    gemm8(b.h8, kVitW, s[2], B.fc, 0, 4 * kVitW, mc, ACT_QUICKGELU, nullptr, 0, nullptr, 4 * kVitW, b.u8, 4 * kVitW, s[3]);
+    gemm8(b.u8, 4 * kVitW, s[3], B.proj, 0, kVitW, mc, ACT_NONE, b.cT, kVitW, b.cT, kVitW, nullptr, 0, 0.f);
+    xpost = b.pre;
+    xpostT = b.cT;
+    ld_post = kVitW;
+  } else if (prune) {
     // Last block: ln_post only reads the cls row (vit.py:186), so everything after the K/V projection is computed
     // for the cls token only (identical values for that row; the other 4 rows of the block output are never read).
     auto& B = h->vit.blk[kVitLayers - 1];
+    constexpr int jl = kVitLayers - 1;
     norm(x, b.xT, kVitW, B.ln1g, B.ln1b, rows, b.hT);
+    cal(jl, 0, b.hT, rows, kVitW);
     GemmArgs kvg;   // K,V of all 5 tokens: in_proj rows [W, 3W)
     kvg.A = b.hT; kvg.lda = kVitW; R.setW(kvg, B.in_proj, kVitW);
     kvg.M = rows; kvg.N = 2 * kVitW; kvg.K = kVitW; kvg.bias = B.in_proj.b + kVitW; kvg.outT = b.qkv; kvg.ldT = 2 * kVitW;
@@ -800,9 +871,12 @@ void vit_chunk(Run& R, const uint8_t* const crops[2], int per_view, int r0, int 
     int e = launch_vit_attn_cls(b.y, b.qkv, b.att, mc, 5, kVitW, kVitHeads, h->bf16, R.st);
     R.prof_end();
     R.other(e, "vit_attn_cls");
+    cal(jl, 1, b.att, mc, kVitW);
     residual(b.att, kVitW, B.out_proj, mc, x, 5 * kVitW, b.pre, b.xT, 5 * kVitW, b.cT, kVitW);   // xc = x_cls + attn
     norm(b.pre, b.cT, kVitW, B.ln2g, B.ln2b, mc, b.hT);
+    cal(jl, 2, b.hT, mc, kVitW);
     R.linear(b.hT, kVitW, B.fc, mc, ACT_QUICKGELU, nullptr, 0, nullptr, 0, nullptr, 0, b.u, 4 * kVitW);
+    cal(jl, 3, b.u, mc, 4 * kVitW);
     residual(b.u, 4 * kVitW, B.proj, mc, b.pre, kVitW, b.pre, b.cT, kVitW, b.cT, kVitW);
     xpost = b.pre;
     xpostT = b.cT;
@@ -843,6 +917,25 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
     vb[i].xT = h->stream_T ? R.wsT((size_t)chunk * 5 * kVitW) : nullptr;
     vb[i].cT = h->stream_T ? R.wsT((size_t)chunk * kVitW) : nullptr;
   }
+  // precision "fp8": chunks whose GEMMs fit the fp8 kernel (full 256x256 tiles; >= 160 of them in the N = 768 GEMMs of the
+  // cls-only last block, M = crops) take fp8 activations once the 16 site scales are calibrated; the first such call calibrates
+  auto fits8 = [&](int mc) { return mc % 256 == 0 && (mc / 256) * (kVitW / 256) >= 160; };
+  const bool can8 = h->a8 && h->bf16 && h->stream_T && h->vit_prune_last && fits8(chunk);
+  const bool calibrate = can8 && !h->vit8_ready;
+  if (calibrate) {
+    if (!h->vit8_amax) {
+      HIPCK(hipMalloc((void**)&h->vit8_amax, kVitLayers * 4 * sizeof(float)));
+      h->owned.push_back(h->vit8_amax);
+    }
+    HIPCK(hipMemsetAsync(h->vit8_amax, 0, kVitLayers * 4 * sizeof(float), R.st));
+    if (dual) { HIPCK(hipStreamSynchronize(R.st)); }   // the auxiliary stream's chunks must see the zeroed slots
+  }
+  if (can8 && h->vit8_ready)
+    for (int i = 0; i < (dual ? 2 : 1); ++i) {
+      vb[i].h8 = R.ws<uint8_t>((size_t)chunk * 5 * kVitW);
+      vb[i].att8 = R.ws<uint8_t>((size_t)chunk * 5 * kVitW);
+      vb[i].u8 = R.ws<uint8_t>((size_t)chunk * 5 * 4 * kVitW);
+    }
   if (R.err) return R.err;
   Run Rb{h, h->aux};
   if (dual && fork_aux(R)) return R.err = 1;
@@ -850,10 +943,20 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
   for (int r0 = 0; r0 < M; r0 += chunk, ++ci) {
     const int mc = (M - r0) < chunk ? (M - r0) : chunk;
     Run& Rc = (dual && (ci & 1)) ? Rb : R;
-    vit_chunk(Rc, crops, per_view, r0, mc, vb[dual ? (ci & 1) : 0], cat);
+    const int f8mode = (can8 && fits8(mc)) ? (h->vit8_ready ? 2 : 1) : 0;
+    vit_chunk(Rc, crops, per_view, r0, mc, vb[dual ? (ci & 1) : 0], cat, f8mode, h->vit8_amax, h->vit8_scale.data());
     if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
   }
   if (dual && join_aux(R)) return R.err = 1;
+  if (calibrate) {
+    std::vector<float> am(kVitLayers * 4);
+    HIPCK(hipMemcpyAsync(am.data(), h->vit8_amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, R.st));
+    HIPCK(hipStreamSynchronize(R.st));
+    h->vit8_scale.resize(am.size());
+    for (size_t i = 0; i < am.size(); ++i) h->vit8_scale[i] = am[i] > 0.f ? am[i] / 448.0f : 1.0f;
+    h->vit8_ready = true;
+    ++h->state_gen;
+  }
   // bbox MLP per view -> cat[:, 768:1536]; then per-view Linear(1536 -> E) scattered to [n, 2qv, E]
   void* t1 = R.wsT((size_t)per_view * 768);
   void* t2 = R.wsT((size_t)per_view * 768);
@@ -906,7 +1009,7 @@ int t5_bias_table(VimaHandle* h, int L, float** out) {
   return 0;
 }
 
-struct T5Buf { void *hT, *qkv, *ctx, *u; float *ssA, *ssB; };   // ssA / ssB: RMS partial sums [rows][24] (fused path)
+struct T5Buf { void *hT, *qkv, *ctx, *u; float *ssA, *ssB; void *h8 = nullptr, *ctx8 = nullptr, *u8 = nullptr; };   // ssA / ssB: RMS partial sums [rows][24] (fused path); *8: fp8 copies (precision "fp8")
 
 void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B, int L,
               const T5Buf& b, int attn_impl) {
@@ -934,10 +1037,50 @@ void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* ma
 //   * sum x^2 comes from the producer's epilogue as 24 per-32-column partials per row (deterministic, no atomics).
 // Entry: b.hT / ssq_in describe the incoming x (`parts_in` partials per row); exit: b.hT and the returned buffer
 // describe the outgoing x (24 partials). Removes two 600-MB HBM passes (fp32 read + bf16 write) per layer at cfg-3.
-const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B,
-                            int L, const T5Buf& b, int attn_impl, const float* ssq_in, int parts_in) {
+// precision "fp8", after calibration: the same fused layer with fp8 e4m3 activations into all four GEMMs (stream_T form only).
+// `sc` = this layer's four dequantisation scales followed by the next layer's first one (0 for the last layer): the residual
+// GEMMs write the fp8 copy of the new stream next to the bf16 stream, wi writes its ReLU hidden in fp8 only; the attention
+// context is quantised by a separate pass (its kernel owns 64 of a row's 768 columns).
+const float* t5_layer_fp8(Run& R, const VimaHandle::T5Layer& Ly, const uint8_t* mask, const float* table, int B, int L, const T5Buf& b,
+                          int attn_impl, const float* ssq_in, int parts_in, const float* sc) {
   const int rows = B * L;
   constexpr int kParts = kT5Model / 32;
+  auto gemm8 = [&](const void* A8, int lda, float ascale, const Lin& W, int act, bool residual, void* outT, int ldT, const float* rs,
+                   int rs_parts, float* ssq_out, void* out8, int ld8, float oscale) {
+    GemmArgs g;
+    g.A = A8; g.lda = lda; g.a8 = 1; g.ascale = ascale; R.setW(g, W); g.M = rows; g.N = W.N; g.K = W.K; g.act = act;
+    if (residual) { g.resT = b.hT; g.ldresT = kT5Model; }
+    g.outT = outT; g.ldT = ldT;
+    g.rs_ssq = rs; g.rs_parts = rs_parts; g.rs_invk = 1.0f / (float)kT5Model; g.rs_eps = 1e-6f;
+    g.ssq_out = ssq_out;
+    if (out8 && oscale > 0.f) { g.out8 = out8; g.ld8 = ld8; g.out8_inv = 1.0f / oscale; }
+    return R.gemm(g);
+  };
+  gemm8(b.h8, kT5Model, sc[0], Ly.qkv_g, ACT_NONE, false, b.qkv, 3 * kT5Model, ssq_in, parts_in, nullptr, nullptr, 0, 0.f);
+  AttnArgs a;
+  a.q = b.qkv; a.ldq = 3 * kT5Model;
+  a.k = R.offT(b.qkv, kT5Model); a.ldk = 3 * kT5Model;
+  a.v = R.offT(b.qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
+  a.out = b.ctx; a.ldo = kT5Model;
+  a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+  a.mode = ATTN_T5;
+  R.attn(a, attn_impl);
+  OTHER(R, launch_quant_fp8(b.ctx, kT5Model, rows, kT5Model, 1.0f / sc[1], b.ctx8, kT5Model, R.st), "quant_fp8");
+  gemm8(b.ctx8, kT5Model, sc[1], Ly.o, ACT_NONE, true, b.hT, kT5Model, nullptr, 0, b.ssA, b.h8, kT5Model, sc[2]);
+  gemm8(b.h8, kT5Model, sc[2], Ly.wi_g, ACT_RELU, false, nullptr, kT5FF, b.ssA, kParts, nullptr, b.u8, kT5FF, sc[3]);
+  gemm8(b.u8, kT5FF, sc[3], Ly.wo, ACT_NONE, true, b.hT, kT5Model, nullptr, 0, b.ssB, b.h8, kT5Model, sc[4]);
+  return b.ssB;
+}
+
+const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B,
+                            int L, const T5Buf& b, int attn_impl, const float* ssq_in, int parts_in, float* amax = nullptr) {
+  const int rows = B * L;
+  constexpr int kParts = kT5Model / 32;
+  // calibration of the fp8 activation scales: max |x| of the four GEMM inputs of this layer (bf16 tensors)
+  auto cal = [&](int site, const void* t, int cols) {
+    if (amax) OTHER(R, launch_amax(t, cols, rows, cols, amax + site, R.st), "amax");
+  };
+  cal(0, b.hT, kT5Model);
   auto gemm = [&](const void* A, int lda, const Lin& W, int act, const float* res, float* out32, void* outT, int ldT,
                   const float* rs, int rs_parts, float* ssq_out) {
     GemmArgs g;
@@ -956,6 +1099,7 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
   a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
   a.mode = ATTN_T5;
   R.attn(a, attn_impl);
+  cal(1, b.ctx, kT5Model);
   if (R.h->stream_T) {
     // The residual stream IS hT (operand type: bf16 in the bf16 / fp8w precisions, fp32 in the parity mode): hT = T(hT + ctx Wo^T)
     // in place, RMS partials of the stored values -> ssA. The fp32 copy `x` is not maintained (4 instead of 10 bytes of HBM
@@ -967,7 +1111,9 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
       return R.gemm(g);
     };
     gemm_s(b.ctx, kT5Model, Ly.o, b.ssA);
+    cal(2, b.hT, kT5Model);
     gemm(b.hT, kT5Model, Ly.wi_g, ACT_RELU, nullptr, nullptr, b.u, kT5FF, b.ssA, kParts, nullptr);
+    cal(3, b.u, kT5FF);
     gemm_s(b.u, kT5FF, Ly.wo, b.ssB);
     return b.ssB;
   }
@@ -996,6 +1142,26 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     buf[i].ssA = R.ws<float>(rows * (kT5Model / 32));
     buf[i].ssB = R.ws<float>(rows * (kT5Model / 32));
   }
+  // precision "fp8": fp8 activations when the four GEMM shapes of a layer fit the fp8 kernel (full 256x256 tiles, >= 160 of them for
+  // the N = 768 GEMMs) and the scales are calibrated; the first pass of a handle calibrates (fp8w kernels + max |x| per site)
+  auto fits8 = [&](int n) { const long long r = (long long)n * L; return n == 0 || (r % 256 == 0 && (r / 256) * (kT5Model / 256) >= 160); };
+  const bool can8 = h->a8 && h->bf16 && h->stream_T && h->t5_fuse_rms && !gemm_splitk_enabled(&h->tune) && fits8(nb[0]) && fits8(nb[1]);
+  const bool run8 = can8 && h->fp8_ready;
+  const bool calibrate = can8 && !h->fp8_ready;
+  if (calibrate) {
+    if (!h->fp8_amax) {
+      HIPCK(hipMalloc((void**)&h->fp8_amax, kT5Layers * 4 * sizeof(float)));
+      h->owned.push_back(h->fp8_amax);
+    }
+    HIPCK(hipMemsetAsync(h->fp8_amax, 0, kT5Layers * 4 * sizeof(float), R.st));
+  }
+  if (run8)
+    for (int i = 0; i < (dual ? 2 : 1); ++i) {
+      const size_t rows = (size_t)nb[i] * L;
+      buf[i].h8 = R.ws<uint8_t>(rows * kT5Model);
+      buf[i].ctx8 = R.ws<uint8_t>(rows * kT5Model);
+      buf[i].u8 = R.ws<uint8_t>(rows * kT5FF);
+    }
   if (R.err) return R.err;
   Run Rb{h, h->aux};
   if (dual && fork_aux(R)) return R.err = 1;
@@ -1013,10 +1179,22 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
       ss[1] = buf[1].ssB;
     }
   }
+  if (run8) {   // entry: fp8 copy of the incoming stream with layer 0's first scale
+    OTHER(R, launch_quant_fp8(buf[0].hT, kT5Model, (long long)nb[0] * L, kT5Model, 1.0f / h->fp8_scale[0], buf[0].h8, kT5Model, R.st), "quant_fp8");
+    if (dual) OTHER(Rb, launch_quant_fp8(buf[1].hT, kT5Model, (long long)nb[1] * L, kT5Model, 1.0f / h->fp8_scale[0], buf[1].h8, kT5Model, Rb.st), "quant_fp8");
+  }
   for (int l = 0; l < kT5Layers; ++l) {
-    if (fused) {
-      ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts);
-      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts);
+    if (run8) {
+      float sc[5];
+      for (int k = 0; k < 4; ++k) sc[k] = h->fp8_scale[l * 4 + k];
+      sc[4] = l + 1 < kT5Layers ? h->fp8_scale[(l + 1) * 4] : 0.f;
+      ss[0] = t5_layer_fp8(R, h->t5[l], mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts, sc);
+      if (dual) ss[1] = t5_layer_fp8(Rb, h->t5[l], mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts, sc);
+      parts = kT5Model / 32;
+    } else if (fused) {
+      float* am = calibrate ? h->fp8_amax + l * 4 : nullptr;
+      ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts, am);
+      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts, am);
       parts = kT5Model / 32;
     } else {
       t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
@@ -1034,6 +1212,15 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
           out32 ? out32 + off1 * kT5Model : nullptr, outT ? R.offT(outT, off1 * kT5Model) : nullptr);
     if (Rb.err) return R.err = Rb.err;
     if (join_aux(R)) return R.err = 1;
+  }
+  if (calibrate && !R.err) {   // one-time: read the 48 maxima back and freeze the scales (amax / 448; a dead site gets 1)
+    std::vector<float> am(kT5Layers * 4);
+    HIPCK(hipMemcpyAsync(am.data(), h->fp8_amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, R.st));
+    HIPCK(hipStreamSynchronize(R.st));
+    h->fp8_scale.resize(am.size());
+    for (size_t i = 0; i < am.size(); ++i) h->fp8_scale[i] = am[i] > 0.f ? am[i] / 448.0f : 1.0f;
+    h->fp8_ready = true;
+    ++h->state_gen;
   }
   return R.err;
 }
@@ -1160,7 +1347,8 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   if (!head_ok(ds) || !head_ok(dx))
     return fail("vima_create: head dim must be 16, 32, 64 or 128 (got " + std::to_string(ds) + "/" + std::to_string(dx) + ")");
   if (E % 64 || E > 1024) return fail("vima_create: embed_dim must be a multiple of 64 and <= 1024");
-  if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16 && cfg->precision != VIMA_PRECISION_FP8W)
+  if (cfg->precision != VIMA_PRECISION_FP32 && cfg->precision != VIMA_PRECISION_BF16 && cfg->precision != VIMA_PRECISION_FP8W &&
+      cfg->precision != VIMA_PRECISION_FP8)
     return fail("vima_create: bad precision");
   if (cfg->n_positions <= 0 || cfg->n_positions > 512 || cfg->xattn_n_positions <= 0) return fail("vima_create: bad table sizes");
   if (cfg->policy_kind < VIMA_POLICY_VIMA || cfg->policy_kind > VIMA_POLICY_FLAMINGO) return fail("vima_create: bad policy_kind");
@@ -1177,7 +1365,8 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out) {
   h->cfg = *cfg;
   h->device = device;
   h->bf16 = cfg->precision != VIMA_PRECISION_FP32;
-  h->w8 = cfg->precision == VIMA_PRECISION_FP8W;
+  h->w8 = cfg->precision == VIMA_PRECISION_FP8W || cfg->precision == VIMA_PRECISION_FP8;
+  h->a8 = cfg->precision == VIMA_PRECISION_FP8;
   if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -1295,8 +1484,19 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "op_stream_T") h->op_stream_T = (int)value;
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
+  else if (k == "fp8_recalibrate") { h->fp8_ready = false; h->vit8_ready = false; h->kv8_ready = false; }   // precision "fp8": measure the activation scales again
   else return fail("vima_set_option: unknown key " + k);
   return 0;
+}
+
+int vima_fp8_act_scales(VimaHandle* h, int group, float* out, int max_n) {
+  if (!h) { (void)fail("null handle"); return -1; }
+  const bool ready = group == 0 ? h->fp8_ready : group == 1 ? h->vit8_ready : group == 2 ? h->kv8_ready : false;
+  if (!ready) return 0;
+  const std::vector<float>& v = group == 0 ? h->fp8_scale : group == 1 ? h->vit8_scale : h->kv8_scale;
+  const int n = (int)v.size();
+  for (int i = 0; i < n && i < max_n; ++i) out[i] = v[i];
+  return n;
 }
 
 int vima_prof_enable(VimaHandle* h, int on) {
@@ -1574,6 +1774,38 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
   if (build_kv)
     OTHER(R, launch_prompt_pos(prompt, stride_b, stride_l, prompt_mask, h->xpos_emb, h->cfg.xattn_n_positions, pT, B, Lp, E,
                                h->bf16, R.st), "prompt_pos");
+  // precision "fp8": the prompt K/V projections (M = B * Lp rows, the only large GEMMs of the decoder) take the prompt in fp8 e4m3 with
+  // one calibrated scale when their shape fits the fp8 kernel; the first such call measures max |prompt + position embedding|
+  void* p8 = nullptr;
+  float kv_scale = 0.f;
+  if (build_kv && h->a8 && h->bf16 && E % 256 == 0 && rp % 256 == 0 && (long long)(rp / 256) * (2 * E / 256) >= 160 && h->dec[0].kv.ws) {
+    if (!h->kv8_ready) {
+      if (!h->kv8_amax) {
+        HIPCK(hipMalloc((void**)&h->kv8_amax, sizeof(float)));
+        h->owned.push_back(h->kv8_amax);
+      }
+      HIPCK(hipMemsetAsync(h->kv8_amax, 0, sizeof(float), R.st));
+      OTHER(R, launch_amax(pT, E, rp, E, h->kv8_amax, R.st), "amax");
+      float am = 0.f;
+      HIPCK(hipMemcpyAsync(&am, h->kv8_amax, sizeof(float), hipMemcpyDeviceToHost, R.st));
+      HIPCK(hipStreamSynchronize(R.st));
+      h->kv8_scale.assign(1, am > 0.f ? am / 448.0f : 1.0f);
+      h->kv8_ready = true;
+      ++h->state_gen;
+    } else {
+      kv_scale = h->kv8_scale[0];
+      p8 = R.ws<uint8_t>((size_t)rp * E);
+      if (R.err) return R.err;
+      OTHER(R, launch_quant_fp8(pT, E, rp, E, 1.0f / kv_scale, p8, E, R.st), "quant_fp8");
+    }
+  }
+  auto kv_proj = [&](Run& Rr, int i, void* KV) {
+    if (!p8) return Rr.linear(pT, E, h->dec[i].kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+    GemmArgs g;
+    g.A = p8; g.lda = E; g.a8 = 1; g.ascale = kv_scale; Rr.setW(g, h->dec[i].kv); g.M = rp; g.N = 2 * E; g.K = E; g.bias = h->dec[i].kv.b;
+    g.outT = KV; g.ldT = 2 * E;
+    return Rr.gemm(g);
+  };
   if (dual) {
     while ((int)h->ev_layer.size() < NL) {
       hipEvent_t e;
@@ -1583,7 +1815,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     if (fork_aux(R)) return 1;
     Run Rb{h, h->aux};
     for (int i = 0; i < NL; ++i) {
-      Rb.linear(pT, E, h->dec[i].kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KVs[i], 2 * E);
+      kv_proj(Rb, i, KVs[i]);
       if (Rb.err) return Rb.err;
       HIPCK(hipEventRecord(h->ev_layer[i], h->aux));
     }
@@ -1596,7 +1828,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     R.linear(qn, E, D.q, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, Qb, E);
     if (dual) HIPCK(hipStreamWaitEvent(R.st, h->ev_layer[i], 0));
     else if (build_kv)   // single stream: project right before use (without a cache all layers share one buffer)
-      R.linear(pT, E, D.kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+      kv_proj(R, i, KV);
     AttnArgs a;
     a.q = Qb; a.ldq = E; a.k = KV; a.ldk = 2 * E; a.v = R.offT(KV, E); a.ldv = 2 * E; a.out = ctx; a.ldo = E;
     a.kmask = prompt_mask; a.B = B; a.H = Hx; a.Lq = Lq; a.Lk = Lp; a.D = E / Hx;

@@ -513,7 +513,7 @@ class VIMAPolicy(nn.Module):
 
     _GEMM_KINDS = {1: "vima::gemm_pp_kernel", 2: "vima::gemm_persistent_kernel", 3: "vima::gemm_wide_kernel",
                    4: "vima::gemm_kernel<Tile<256, 256>>", 5: "vima::gemm_kernel<Tile<128, 128>>", 6: "vima::gemm_kernel<Tile<64, 64>>",
-                   7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)"}
+                   7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)", 9: "vima::gemm_pp_kernel"}
 
     def prof_read_gemm_kernels(self):
         """GEMM launches recorded since prof_enable(True), grouped by the kernel the launcher chose (call BEFORE prof_read /
@@ -532,9 +532,26 @@ class VIMAPolicy(nn.Module):
             kind, rest = divmod(int(ids[i]), 1000)
             act, epi = divmod(rest, 10)
             base = self._GEMM_KINDS.get(kind, f"gemm kind {kind}")
-            name = f"{base}<{act - 1}, {epi}>" if kind in (1, 2, 3) else f"{base} act {act - 1}"
+            if kind == 9:
+                name = f"{base}<{act - 1}, {epi}, true>"          # fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
+            elif kind == 1:
+                name = f"{base}<{act - 1}, {epi}, false>"
+            else:
+                name = f"{base}<{act - 1}, {epi}>" if kind in (2, 3) else f"{base} act {act - 1}"
             out[name] = {"ms": ms[i], "launches": int(ln[i]), "flops": fl[i], "bytes": by[i]}
         return out
+
+    def fp8_act_scales(self, group: str = "t5"):
+        """precision "fp8": the calibrated activation scales of a group -- "t5" [12, 4], "vit" [4, 4] or "kv" [1] -- or None before
+        that group's calibrating pass."""
+        buf = (ctypes.c_float * 64)()
+        n = self._lib.vima_fp8_act_scales(self._handle, {"t5": 0, "vit": 1, "kv": 2}[group], buf, 64)
+        if n < 0:
+            _lib.check(1)
+        if n == 0:
+            return None
+        t = torch.tensor(list(buf[:n]))
+        return t.view(-1, 4) if group != "kv" else t
 
     def workspace_bytes(self) -> int:
         return int(self._lib.vima_workspace_bytes(self._handle)) if self._handle is not None else 0
