@@ -52,9 +52,10 @@ def test_hot_kernels_use_no_scratch(src, patterns):
     hot = {k: v for k, v in res.items() if any(p in k for p in patterns) and "ELb0ELb1ELb0EEEv" not in k}
     assert hot, f"no kernel of {src} matched {patterns}"
     for k, v in hot.items():
-        # the fp8-weight GEGLU instantiation (gemm_persistent_kernel<GELU, gate, W8>) keeps 5 tile-invariant address
-        # registers in scratch (stored once per launch, reloaded once per tile, outside the K loop); not on the bench path
-        allowed = 32 if "gemm_persistent_kernelILi2ELi2ELb1" in k else 0
+        # the fp8-WEIGHT instantiations of the round-2 persistent kernel (gemm_persistent_kernel<.., W8 = true>: precision fp8w and the
+        # calibrating pass of precision fp8) keep a few tile-invariant address registers in scratch (stored once per launch, reloaded
+        # once per tile, outside the K loop); they are not on the bench path (bf16 and fp8 run gemm_pp_kernel, which must be scratch-free)
+        allowed = 32 if re.search(r"gemm_persistent_kernelILi\dELi\dELb1", k) else 0
         assert v.get("ScratchSize", 0) <= allowed, (k, v)
         assert v.get("VGPRs", 0) + v.get("AGPRs", 0) <= 256, (k, v)     # two waves per SIMD for the 512-thread GEMMs
 
