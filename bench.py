@@ -419,8 +419,10 @@ def main():
                 "roofline_ms": round(max(t_mfma, t_hbm), 4), "frac": round(max(t_mfma, t_hbm) / ms, 4),
                 "algorithmic_tflop": round(flops / 1e12, 3), "kv_stream_mb": round(kv_bytes / 1e6, 1)}
 
-    warm_roof = small_roofline(warm_ms, B * warm)
-    inc_roof = small_roofline(inc_ms, B * warm)
+    # executed FLOPs of a WARM / incremental step: the per-layer prompt K/V projection (2 * Lp * 2E * E per sample and layer) is cached
+    kv_proj_flops = cfg.xf_n_layers * 2.0 * args.prompt_len * 2 * cfg.embed_dim * cfg.embed_dim
+    warm_roof = small_roofline(warm_ms, B * (warm - kv_proj_flops))
+    inc_roof = small_roofline(inc_ms, B * (warm - kv_proj_flops))
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:          # timed on rank 0's host cores, outside the timed region, for every N
