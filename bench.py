@@ -235,9 +235,12 @@ def main():
 
     # ---- N ranks: `--gpus N` without a torchrun environment re-launches this script under torch.distributed.run with one
     # rank per GPU; it never silently measures fewer GPUs than asked for.
+    # VIMA_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the ranks talk over gloo, so that the self-relaunch / rank
+    # agreement / max-over-ranks path below can be EXECUTED on a one-GPU box; the printed line is marked and is not a measurement
+    shared_gpu = os.environ.get("VIMA_BENCH_SHARED_GPU") == "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         visible = torch.cuda.device_count()
-        if visible < args.gpus:
+        if visible < args.gpus and not shared_gpu:
             sys.exit(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible on this node; refusing to "
                      f"print a {visible}-GPU number as a {args.gpus}-GPU result")
         import socket
@@ -254,6 +257,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if shared_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     import torch.distributed as dist
@@ -263,13 +268,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()                  # the LIVE RCCL world size is what gets reported as n_gpus
 
     from vima_amd import synthetic as syn, parallel
     from vima_amd.policy import VIMAPolicy
     collective = None
-    if world > 1:
+    if world > 1 and shared_gpu:
+        collective = "torch.distributed all_gather over gloo (VIMA_BENCH_SHARED_GPU test mode: ranks share one GPU, RCCL refuses that)"
+    elif world > 1:
         # RCCL communicator behind the C ABI (vima_allgather_logits). Every rank must take the same path: agree on success
         # through the torch.distributed group; if any rank failed to create it, all fall back to torch.distributed's own
         # all-gather (also RCCL) and the line says so.
@@ -442,7 +452,8 @@ def main():
                        "warm_ms_per_step": round(warm_ms, 3) if warm_ms == warm_ms else None, "warm_steps_per_s": round(world * 1e3 / warm_ms, 2) if warm_ms == warm_ms else None,
                        "incremental_env_step_ms": round(inc_ms, 3) if inc_ms == inc_ms else None,
                        "warm_roofline": warm_roof, "incremental_roofline": inc_roof,
-                       "secondary_cold": secondary},
+                       "secondary_cold": secondary,
+                       **({"shared_gpu_test": "all ranks on GPU 0 over gloo: exercises the launcher path, NOT a multi-GPU measurement"} if shared_gpu else {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

@@ -131,6 +131,14 @@ int vima_decode(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, co
 int vima_decode_step(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, int step, int B,
                      int Q, const float* prompt, int64_t stride_b, int64_t stride_l, const uint8_t* prompt_mask,
                      int Lp, float* out, vima_stream_t stream);
+/* Per-sample episode restart inside a running batch of incremental decoding (no reference counterpart: scripts/example.py:97-110 runs
+ * one episode at a time; batched environments end their episodes at different steps). For every sample with restart[b] != 0 (HOST
+ * array of B bytes): its cached history is masked out, its position counter restarts at 0, its next step has no previous action, and
+ * its rows of the per-layer prompt K/V cache are rebuilt from ITS row of `prompt` / `prompt_mask` (the new episode's prompt; layout and
+ * strides as in vima_decode_step; rows of the other samples are not read). The batch then keeps calling vima_decode_step with
+ * step + 1 (pass any act_tok row for restarted samples: it is ignored). n_positions still bounds the steps since the batch's step 0. */
+int vima_decode_restart(VimaHandle* h, const uint8_t* restart, int B, const float* prompt, int64_t stride_b, int64_t stride_l,
+                        const uint8_t* prompt_mask, int Lp, vima_stream_t stream);
 
 /* VIMAPolicy.forward_action_decoder (vima_policy.py:264-265 -> action_decoder.py:51-52,165-166): tokens f32 [R,E]
  * -> raw logits f32 [R,700] = concat over keys (pose0_position, pose0_rotation, pose1_position, pose1_rotation) of

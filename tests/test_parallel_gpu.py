@@ -99,3 +99,24 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0
     assert '"metric"' not in r.stdout, "bench.py printed a result line although fewer GPUs than requested are visible"
     assert "requested but only" in (r.stderr + r.stdout)
+
+
+def test_bench_launcher_path_with_two_ranks_on_the_one_gpu():
+    """`bench.py --gpus 2` re-launches itself under torch.distributed.run, the ranks agree on the collective,
+    time the same steps, take the maximum over ranks and rank 0 prints ONE line with the live world size. Only one GPU is reachable
+    here and RCCL refuses two ranks on one device, so the test mode VIMA_BENCH_SHARED_GPU=1 puts both ranks on GPU 0 over gloo (tiny
+    model); the line is marked as a launcher test, not a measurement."""
+    import json
+    env = dict(os.environ, VIMA_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "2M",
+                        "--batch", "4", "--prompt-len", "64", "--qv", "2", "--words", "4", "--headline-only"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert "gloo" in d["config"]["collective"] and "shared_gpu_test" in d["config"]
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["cores"] >= 1      # carried into N > 1 lines
+    assert d["value"] > 0 and d["ms_per_step"] > 0

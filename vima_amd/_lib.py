@@ -43,6 +43,7 @@ PROTOTYPES = {
                                    vp, c_i64, c_i64, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "vima_decode_step": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, c_i64, c_i64, vp,
                                         ctypes.c_int, vp, vp]),
+    "vima_decode_restart": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, c_i64, c_i64, vp, ctypes.c_int, vp]),
     "vima_rgb_tokens_per_image": (ctypes.c_int, [ctypes.POINTER(VimaConfig)]),
     "vima_rgb_encode": (ctypes.c_int, [vp, vp * 2, ctypes.c_int, vp, vp]),
     "vima_rgb_obs_encode": (ctypes.c_int, [vp, vp * 2, vp, ctypes.c_int, vp, vp]),

@@ -296,14 +296,17 @@ __global__ __launch_bounds__(256) void dec_embed_step_kernel(const float* __rest
                                                               const float* __restrict__ act_tok,
                                                               const float* __restrict__ pos_table, int n_pos, float* x32,
                                                               T* xT, uint8_t* hist_mask, int* poscnt, int L_hist, int Lmax,
-                                                              int Q, int has_act, int E) {
+                                                              int Q, int has_act, int E, uint8_t* fresh) {
   __shared__ int pos_s[64];
   const int b = blockIdx.x;
   const int Ln = Q + has_act;
   if (threadIdx.x == 0) {
     int run = poscnt[b];
+    // a sample restarted by vima_decode_restart has no previous action: its action slot of this step is a masked (invalid) token
+    const int fr = fresh ? fresh[b] : 0;
+    if (fr) fresh[b] = 0;
     for (int i = 0; i < Ln; ++i) {
-      const int mk = (has_act && i == 0) ? 1 : (obs_mask[(long long)b * Q + (i - has_act)] ? 1 : 0);
+      const int mk = (has_act && i == 0) ? (fr ? 0 : 1) : (obs_mask[(long long)b * Q + (i - has_act)] ? 1 : 0);
       run += mk;
       int p = run - 1;
       p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
@@ -324,6 +327,16 @@ __global__ __launch_bounds__(256) void dec_embed_step_kernel(const float* __rest
     store4(x32 + off, o);
     if (xT) store4(xT + off, o);
   }
+}
+
+// per-sample episode restart (vima_decode_restart): flagged samples forget their history (every cached key masked), their position
+// counter restarts at 0 and their next step's action slot is marked absent
+__global__ __launch_bounds__(256) void restart_samples_kernel(const uint8_t* __restrict__ flags, uint8_t* hist_mask, int* poscnt, uint8_t* fresh,
+                                                               int Lmax) {
+  const int b = blockIdx.x;
+  if (!flags[b]) return;
+  for (int i = threadIdx.x; i < Lmax; i += 256) hist_mask[(long long)b * Lmax + i] = 0;
+  if (threadIdx.x == 0) { poscnt[b] = 0; fresh[b] = 1; }
 }
 
 // prompt + xattn_positions_embed[cumsum(prompt_mask) - 1]  (vima_policy.py:147, xattn_gpt.py:110-114) -> T [B, Lp, E]
@@ -583,15 +596,21 @@ int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float*
 
 int launch_dec_embed_step(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table, int n_pos,
                           float* x32, void* xT, uint8_t* hist_mask, int* poscnt, int L_hist, int Lmax, int B, int Q,
-                          int has_act, int E, bool is_bf16, hipStream_t st) {
+                          int has_act, int E, bool is_bf16, hipStream_t st, uint8_t* fresh) {
   if (B <= 0) return 0;
   if (Q + has_act > 64 || E % 4 || L_hist + Q + has_act > Lmax) return (int)hipErrorInvalidValue;
   if (is_bf16)
     hipLaunchKernelGGL(dec_embed_step_kernel<bf16_t>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
-                       x32, (bf16_t*)xT, hist_mask, poscnt, L_hist, Lmax, Q, has_act, E);
+                       x32, (bf16_t*)xT, hist_mask, poscnt, L_hist, Lmax, Q, has_act, E, fresh);
   else
     hipLaunchKernelGGL(dec_embed_step_kernel<float>, dim3(B), dim3(256), 0, st, obs_tok, obs_mask, act_tok, pos_table, n_pos,
-                       x32, (float*)xT, hist_mask, poscnt, L_hist, Lmax, Q, has_act, E);
+                       x32, (float*)xT, hist_mask, poscnt, L_hist, Lmax, Q, has_act, E, fresh);
+  return (int)hipGetLastError();
+}
+
+int launch_restart_samples(const uint8_t* flags, uint8_t* hist_mask, int* poscnt, uint8_t* fresh, int B, int Lmax, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(restart_samples_kernel, dim3(B), dim3(256), 0, st, flags, hist_mask, poscnt, fresh, Lmax);
   return (int)hipGetLastError();
 }
 

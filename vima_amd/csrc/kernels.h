@@ -137,7 +137,10 @@ int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float*
 // [B, Q+has_act, E]; position ids continue poscnt[b]; hist_mask[b][L_hist + i] and poscnt[b] are updated
 int launch_dec_embed_step(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table, int n_pos,
                           float* x32, void* xT, uint8_t* hist_mask, int* poscnt, int L_hist, int Lmax, int B, int Q,
-                          int has_act, int E, bool is_bf16, hipStream_t st);
+                          int has_act, int E, bool is_bf16, hipStream_t st, uint8_t* fresh = nullptr);
+// per-sample episode restart: for flags[b] != 0 (device array) mask sample b's whole history, reset its position counter, mark its
+// next action slot absent (fresh[b] = 1, consumed by launch_dec_embed_step)
+int launch_restart_samples(const uint8_t* flags, uint8_t* hist_mask, int* poscnt, uint8_t* fresh, int B, int Lmax, hipStream_t st);
 // prompt + xattn_positions_embed[cumsum(mask)-1] -> T [B*Lp, E]; input strides in elements (seq-first views ok)
 int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uint8_t* mask, const float* pos_table,
                       int n_pos, void* outT, int B, int Lp, int E, bool is_bf16, hipStream_t st);

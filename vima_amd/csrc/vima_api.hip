@@ -195,6 +195,7 @@ struct VimaHandle {
   // type), its key mask [B][ep_Lmax] and the per-sample count of valid tokens (next position id)
   void* ep_kv = nullptr; size_t ep_kv_bytes = 0;
   uint8_t* ep_mask = nullptr; int* ep_poscnt = nullptr; size_t ep_aux_cap = 0;
+  uint8_t* ep_fresh = nullptr;   // [B] 1 = the sample was restarted (vima_decode_restart): its next step has no previous action
   int ep_B = 0, ep_Q = 0, ep_Lmax = 0, ep_Lp = 0, ep_step = -1;
   // hipGraph replay of the per-env-step entry points (option "graphs"): at small batch a step is ~1300 launches of
   // microsecond kernels and the HOST launch rate is the bound. The launch sequence of a call is captured the second time
@@ -1328,7 +1329,7 @@ int run_graphed(VimaHandle* h, std::string key, hipStream_t user, F&& fn) {
 // =================================================================================================== C ABI
 extern "C" {
 
-int vima_abi_version(void) { return 3; }   // 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w; 3: + VimaConfig.policy_kind, baseline-policy entry points
+int vima_abi_version(void) { return 4; }   // 4: + precision fp8 (VIMA_PRECISION_FP8, vima_fp8_act_scales), vima_decode_restart, vima_prof_read_gemm_kernels ; 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w; 3: + VimaConfig.policy_kind, baseline-policy entry points
 const char* vima_last_error(void) { return g_err.c_str(); }
 int vima_t5_bucket(int rel) { return t5_bucket(rel); }
 void vima_fp8_e4m3_encode(const float* src, uint8_t* dst, int64_t n) {
@@ -1389,6 +1390,7 @@ void vima_destroy(VimaHandle* h) {
   if (h->ep_kv) (void)hipFree(h->ep_kv);
   if (h->ep_mask) (void)hipFree(h->ep_mask);
   if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
+  if (h->ep_fresh) (void)hipFree(h->ep_fresh);
   drop_graphs(h);
   if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
   if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
@@ -1689,10 +1691,12 @@ static int decode_prepare(VimaHandle* h, const float* act_tok, int T, int B, int
         if (h->ep_kv) (void)hipFree(h->ep_kv);
         if (h->ep_mask) (void)hipFree(h->ep_mask);
         if (h->ep_poscnt) (void)hipFree(h->ep_poscnt);
-        h->ep_kv = nullptr; h->ep_mask = nullptr; h->ep_poscnt = nullptr; h->ep_kv_bytes = 0; h->ep_aux_cap = 0;
+        if (h->ep_fresh) (void)hipFree(h->ep_fresh);
+        h->ep_kv = nullptr; h->ep_mask = nullptr; h->ep_poscnt = nullptr; h->ep_fresh = nullptr; h->ep_kv_bytes = 0; h->ep_aux_cap = 0;
         HIPCK(hipMalloc(&h->ep_kv, need));
         HIPCK(hipMalloc((void**)&h->ep_mask, (size_t)B * Lmax));
         HIPCK(hipMalloc((void**)&h->ep_poscnt, (size_t)B * sizeof(int)));
+        HIPCK(hipMalloc((void**)&h->ep_fresh, (size_t)B));
         h->ep_kv_bytes = need; h->ep_aux_cap = (size_t)B * Lmax;
         ++h->state_gen;
       }
@@ -1731,7 +1735,10 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
   const int E = h->cfg.embed_dim;
   const bool inc = P.inc;
   const int has_act = P.has_act, L_hist = P.L_hist, Lq = P.Lq, Lmax = P.Lmax, kv_cache_mode = P.kv_mode;
-  if (inc && L_hist == 0) HIPCK(hipMemsetAsync(h->ep_poscnt, 0, (size_t)B * sizeof(int), stream));
+  if (inc && L_hist == 0) {
+    HIPCK(hipMemsetAsync(h->ep_poscnt, 0, (size_t)B * sizeof(int), stream));
+    HIPCK(hipMemsetAsync(h->ep_fresh, 0, (size_t)B, stream));
+  }
   Run R{h, (hipStream_t)stream};
   const int rq = B * Lq, rp = B * Lp;
   const int Hx = h->cfg.xattn_n_heads, Hs = h->cfg.sattn_n_heads;
@@ -1767,7 +1774,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
   if (R.err) return R.err;
   if (inc)
     OTHER(R, launch_dec_embed_step(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, h->ep_mask, h->ep_poscnt,
-                                   L_hist, Lmax, B, Q, has_act, E, h->bf16, R.st), "dec_embed_step");
+                                   L_hist, Lmax, B, Q, has_act, E, h->bf16, R.st, h->ep_fresh), "dec_embed_step");
   else
     OTHER(R, launch_dec_embed(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, dmask, T, B, Q, L_act, E,
                               h->bf16, R.st), "dec_embed");
@@ -1907,6 +1914,38 @@ int vima_decode_step(VimaHandle* h, const float* obs_tok, const uint8_t* obs_mas
   });
   if (!rc) decode_commit(h, P, B, Q, Lp, step);
   return rc;
+}
+
+// Per-sample episode restart inside a running batch of incremental decoding (batched environments whose episodes end at different
+// steps; scripts/example.py:97-110 starts a new episode with a new prompt). For every sample with restart[b] != 0 (HOST array): its
+// cached history is masked out (the caches keep ONE row index space for the batch: the next step's tokens of all samples still land
+// at the same cache rows), its position counter restarts at 0, its next step carries no previous action, and its rows of the per-layer
+// prompt K/V cache are rebuilt from its row of `prompt` (the NEW prompts; rows of the other samples are not read). The batch keeps
+// stepping with vima_decode_step(step + 1, ...); n_positions bounds the number of steps since the last step 0 of the whole batch.
+int vima_decode_restart(VimaHandle* h, const uint8_t* restart, int B, const float* prompt, int64_t stride_b, int64_t stride_l,
+                        const uint8_t* prompt_mask, int Lp, vima_stream_t stream) {
+  if (int e = check_ready(h)) return e;
+  if (!restart || !prompt || !prompt_mask) return fail("vima_decode_restart: null argument");
+  if (!(h->ep_step >= 0 && h->ep_B == B && h->ep_Lp == Lp && h->kv_valid && h->kv_B == B && h->kv_Lp == Lp))
+    return fail("vima_decode_restart: no running episode batch with this B / Lp (start one with vima_decode_step(step = 0))");
+  const int E = h->cfg.embed_dim, NL = h->cfg.xf_n_layers;
+  Run R{h, (hipStream_t)stream};
+  uint8_t* flags = R.ws<uint8_t>((size_t)B);
+  void* pT = R.wsT((size_t)Lp * E);
+  if (R.err) return R.err;
+  HIPCK(hipMemcpyAsync(flags, restart, (size_t)B, hipMemcpyHostToDevice, R.st));
+  OTHER(R, launch_restart_samples(flags, h->ep_mask, h->ep_poscnt, h->ep_fresh, B, h->ep_Lmax, R.st), "restart_samples");
+  const size_t kv_layer_bytes = (size_t)B * Lp * 2 * E * h->esz();
+  for (int b = 0; b < B && !R.err; ++b) {
+    if (!restart[b]) continue;
+    OTHER(R, launch_prompt_pos(prompt + (long long)b * stride_b, stride_b, stride_l, prompt_mask + (long long)b * Lp, h->xpos_emb,
+                               h->cfg.xattn_n_positions, pT, 1, Lp, E, h->bf16, R.st), "prompt_pos");
+    for (int i = 0; i < NL; ++i) {
+      void* KV = reinterpret_cast<char*>(h->kv_cache) + kv_layer_bytes * i + (size_t)b * Lp * 2 * E * h->esz();
+      R.linear(pT, E, h->dec[i].kv, Lp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+    }
+  }
+  return R.err;
 }
 
 // ---- baseline policies --------------------------------------------------------------------------

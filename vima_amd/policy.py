@@ -418,6 +418,25 @@ class VIMAPolicy(nn.Module):
             prompt_token.stride(1), prompt_token.stride(0), _ptr(prompt_token_mask), Lp, _ptr(out), self._stream()))
         return out
 
+    def restart_samples(self, restart, prompt_token: torch.Tensor, prompt_token_mask: torch.Tensor):
+        """Per-sample episode restart inside a batch that is stepping with `forward_step` (batched environments finish their
+        episodes at different steps): for every sample with `restart[b]` true its cached history is forgotten, its position ids
+        restart at 0, its next `forward_step` ignores the previous-action token, and its prompt K/V cache rows are rebuilt from
+        `prompt_token[:, b]` / `prompt_token_mask[b]` (the new episode's prompt, same [Lp, B, E] / [B, Lp] layout as `forward_step`;
+        other samples' rows are not read). Keep calling `forward_step(..., step=previous + 1)` with the UPDATED prompt tensors."""
+        self._ready()
+        dev = self._device
+        flags = torch.as_tensor(restart).to(dtype=torch.uint8, device="cpu").contiguous()
+        if prompt_token.stride(-1) != 1:
+            prompt_token = prompt_token.contiguous()
+        prompt_token = prompt_token.to(dev)
+        prompt_token_mask = prompt_token_mask.to(device=dev, dtype=torch.bool).contiguous()
+        Lp, B = prompt_token.shape[0], prompt_token.shape[1]
+        assert flags.numel() == B
+        self._kv_key = None
+        _lib.check(self._lib.vima_decode_restart(self._handle, ctypes.c_void_p(flags.data_ptr()), B, _ptr(prompt_token),
+                                                 prompt_token.stride(1), prompt_token.stride(0), _ptr(prompt_token_mask), Lp, self._stream()))
+
     # ------------------------------------------------------------------ actions
     def action_logits(self, predicted_action_tokens: torch.Tensor) -> torch.Tensor:
         """Raw concatenated logits [..., 700] of the 12 action-head MLPs (input of MultiCategoricalHead,
