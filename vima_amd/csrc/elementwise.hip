@@ -2,6 +2,7 @@
 // token plumbing. Each cites the reference lines it replaces. fp32 statistics everywhere; the operand type T of
 // the matrix-core GEMMs (bf16, or fp32 in parity mode) only appears at the GEMM-input boundary.
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace vima {
 namespace {
@@ -64,6 +65,97 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
       if (out32) store4(out32 + (long long)row * E + c * 4, o);
       if (outT) store4(outT + (long long)row * E + c * 4, o);
       if (out8) *reinterpret_cast<uint32_t*>(out8 + (long long)row * E + c * 4) = pack4_fp8(o, inv8);   // precision "fp8": e4m3 copy
+    }
+  }
+}
+
+// bf16 -> bf16 (+ optional e4m3) LayerNorm over rows of E = 256 * NV elements, the shape of the ViT / decoder stream LayerNorms of a
+// big batch (46 launches of 180 MB per B = 256 step). HALF a wave owns a row: every lane loads NV 16-byte chunks (the one-wave-per-row
+// kernel above issues 8-byte loads and retires a wave per row: 4.1 TB/s), a wave walks row pairs with a grid-sized stride and has the
+// NEXT pair's loads in flight while it reduces and stores the current one; gamma / beta live in registers for the whole launch.
+// Same two-pass statistics in fp32 (mean, then centred squares); the sums are taken in this kernel's own fixed order, which does not
+// depend on the number of rows (batch-composition invariance).
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_rows2_kernel(const bf16_t* in, long long ldin, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int rms, int rows, float* out32,
+                                                               bf16_t* outT, uint8_t* out8, float inv8) {
+  constexpr int E = 256 * NV;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const long long nwaves = (long long)gridDim.x * 4;
+  long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long npairs = ((long long)rows + 1) >> 1;
+  if (pair >= npairs) return;
+  float4 g[NV][2], bt[NV][2];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 32 + l31) * 8;
+    g[i][0] = load4(gamma + c); g[i][1] = load4(gamma + c + 4);
+    if (beta) { bt[i][0] = load4(beta + c); bt[i][1] = load4(beta + c + 4); }
+    else { bt[i][0] = make_float4(0.f, 0.f, 0.f, 0.f); bt[i][1] = bt[i][0]; }
+  }
+  auto fetch = [&](long long pr, uint4 (&u)[NV]) {
+    long long r = pr * 2 + half;
+    r = r < rows ? r : rows - 1;
+    const bf16_t* x = in + r * ldin;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) u[i] = *reinterpret_cast<const uint4*>(x + (i * 32 + l31) * 8);
+  };
+  uint4 cur[NV], nxt[NV];
+  fetch(pair, cur);
+  for (; pair < npairs; pair += nwaves) {
+    const bool more = pair + nwaves < npairs;
+    if (more) fetch(pair + nwaves, nxt);
+    float x[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const uint32_t w[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[i][2 * j] = __uint_as_float(w[j] << 16);
+        x[i][2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+      }
+      s += ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
+    }
+    float mean = 0.f;
+    if (!rms) mean = half_wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[i][j] -= mean;
+      q += ((x[i][0] * x[i][0] + x[i][1] * x[i][1]) + (x[i][2] * x[i][2] + x[i][3] * x[i][3])) +
+           ((x[i][4] * x[i][4] + x[i][5] * x[i][5]) + (x[i][6] * x[i][6] + x[i][7] * x[i][7]));
+    }
+    const float rstd = rsqrtf(half_wave_sum(q) / (float)E + eps);
+    const long long row = pair * 2 + half;
+    if (row < rows) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float4 o0, o1;
+        o0.x = x[i][0] * rstd * g[i][0].x + bt[i][0].x; o0.y = x[i][1] * rstd * g[i][0].y + bt[i][0].y;
+        o0.z = x[i][2] * rstd * g[i][0].z + bt[i][0].z; o0.w = x[i][3] * rstd * g[i][0].w + bt[i][0].w;
+        o1.x = x[i][4] * rstd * g[i][1].x + bt[i][1].x; o1.y = x[i][5] * rstd * g[i][1].y + bt[i][1].y;
+        o1.z = x[i][6] * rstd * g[i][1].z + bt[i][1].z; o1.w = x[i][7] * rstd * g[i][1].w + bt[i][1].w;
+        const long long off = row * E + (i * 32 + l31) * 8;
+        if (out32) { store4(out32 + off, o0); store4(out32 + off + 4, o1); }
+        if (outT) {
+          uint4 o;
+          o.x = pack2_bf16(o0.x, o0.y); o.y = pack2_bf16(o0.z, o0.w); o.z = pack2_bf16(o1.x, o1.y); o.w = pack2_bf16(o1.z, o1.w);
+          *reinterpret_cast<uint4*>(outT + off) = o;
+        }
+        if (out8) *reinterpret_cast<uint2*>(out8 + off) = make_uint2(pack4_fp8(o0, inv8), pack4_fp8(o1, inv8));
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
     }
   }
 }
@@ -481,6 +573,12 @@ int launch_amax(const void* inT, long long ldin, long long rows, int cols, float
   return (int)hipGetLastError();
 }
 
+// A/B switch of the half-wave-per-row LayerNorm (environment VIMA_LN_ROWS2=0 restores the one-wave-per-row kernel)
+static bool ln_rows2_enabled() {
+  static const bool on = [] { const char* e = getenv("VIMA_LN_ROWS2"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st) {
   if (rows <= 0) return 0;
@@ -502,6 +600,20 @@ int launch_layernorm_T(const void* inT, long long ldin, const float* gamma, cons
   }
   if (rows <= 0) return 0;
   if (E % 4 != 0 || E > 64 * 4 * LN_MAXV || ldin % 4 != 0) return (int)hipErrorInvalidValue;
+  // the choice depends on the row LENGTH and layout only, never on the number of rows: a row is normalised by the same
+  // instruction sequence whatever batch it arrives in
+  if (E % 256 == 0 && ldin % 8 == 0 && ln_rows2_enabled()) {
+    unsigned g = nblk((rows + 1) / 2, 4);
+    if (g > 2048) g = 2048;
+    const bf16_t* x = (const bf16_t*)inT;
+    switch (E / 256) {
+      case 1: hipLaunchKernelGGL(layernorm_rows2_kernel<1>, dim3(g), dim3(256), 0, st, x, ldin, gamma, beta, eps, rms, rows, out32, (bf16_t*)outT, (uint8_t*)out8, inv8); break;
+      case 2: hipLaunchKernelGGL(layernorm_rows2_kernel<2>, dim3(g), dim3(256), 0, st, x, ldin, gamma, beta, eps, rms, rows, out32, (bf16_t*)outT, (uint8_t*)out8, inv8); break;
+      case 3: hipLaunchKernelGGL(layernorm_rows2_kernel<3>, dim3(g), dim3(256), 0, st, x, ldin, gamma, beta, eps, rms, rows, out32, (bf16_t*)outT, (uint8_t*)out8, inv8); break;
+      default: hipLaunchKernelGGL(layernorm_rows2_kernel<4>, dim3(g), dim3(256), 0, st, x, ldin, gamma, beta, eps, rms, rows, out32, (bf16_t*)outT, (uint8_t*)out8, inv8); break;
+    }
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const bf16_t*)inT, ldin, gamma, beta,
                      eps, rms, rows, E, out32, (bf16_t*)outT, (uint8_t*)out8, inv8);
   return (int)hipGetLastError();
