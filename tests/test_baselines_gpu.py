@@ -118,6 +118,13 @@ def test_baseline_entry_points_reject_the_wrong_policy_kind():
     mask = torch.ones(2, 500, dtype=torch.bool, device=DEV)
     with pytest.raises(IndexError):
         pol.forward(torch.zeros(1, 2, 16, 256, device=DEV), None, long_prompt, mask)
+    # a sample without any valid prompt token: the reference builds position id -1 for it and its embedding lookup raises
+    # (vima_gato_policy.py:156-170); the host mirror refuses the batch the same way (the C entry point is asynchronous and clamps)
+    short = torch.zeros(8, 2, 256, device=DEV)
+    m2 = torch.ones(2, 8, dtype=torch.bool, device=DEV)
+    m2[1] = False
+    with pytest.raises(IndexError):
+        pol.forward(torch.zeros(1, 2, 16, 256, device=DEV), None, short, m2)
 
 
 def test_flamingo_incremental_decoding_matches_full_history():

@@ -137,6 +137,11 @@ class _BaselinePolicy(VIMAPolicy):
         prompt_token = prompt_token.to(device=dev, dtype=torch.float32)
         prompt_token_mask = prompt_token_mask.to(device=dev, dtype=torch.bool).contiguous()
         Lp = prompt_token.shape[0]
+        # the reference builds the position ids on the host from the per-sample number of valid prompt tokens
+        # (vima_gato_policy.py:156-184, one `.item()` per sample); a sample without any valid prompt token gets the id -1 there and the
+        # embedding lookup raises. The C entry point is asynchronous and clamps instead, so the same refusal happens here.
+        if not bool(prompt_token_mask.any(dim=1).all()):
+            raise IndexError("index out of range in self (a sample has no valid prompt token: position id -1, vima_gato_policy.py:164)")
         out = torch.empty(L_obs, B, E, dtype=torch.float32, device=dev)
         _lib.check(self._lib.vima_seq_decode(
             self._handle, _ptr(obs_token), _ptr(action_token), L_obs, B, L_act, _ptr(prompt_token), prompt_token.stride(1),

@@ -21,23 +21,31 @@ namespace vima {
 namespace {
 
 // =============================================================================================== ViT (S <= 8, D = 32)
-template <typename T>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, long long total,
-                                                        int S, int W, int heads, uint8_t* out8 = nullptr, float inv8 = 1.0f) {
+// One (crop, query token, head) of nn.MultiheadAttention over a 5-token crop sequence, everything in registers. ONE body for the
+// three kernels below (operands from global memory, from LDS, cls query only): the last ViT block may be evaluated for the cls row
+// alone (vit_prune_last) and must give the bits the full block gives, so the arithmetic is pinned -- explicit fmaf for the dot
+// products and the weighted sum, no contraction of anything else (the same source compiled into different kernels was otherwise
+// contracted differently: 4.6e-3 on the object tokens between the LDS-staged kernel and the per-thread one).
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
+__device__ __forceinline__ void ld8(const float* p, float* f) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// q: the query's 32 values; krow(j) / vrow(j): pointer to the 32 values of key / value row j of this head; o: the 32 outputs
+template <typename T, typename KR, typename VR>
+__device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, VR vrow, float (&o)[32]) {
+#pragma clang fp contract(off)
   constexpr int D = 32;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int h = (int)(idx % heads);
-  const long long mi = idx / heads;       // m * S + i
-  const long long m = mi / S;
-  const int ld = 3 * W;
-  const T* qp = qkv + mi * ld + h * D;
   float q[D];
 #pragma unroll
-  for (int c = 0; c < D; c += 4) {
-    const float4 v = load4(qp + c);
-    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
-  }
+  for (int c = 0; c < D; c += 8) ld8(qp + c, q + c);
   const float scale = 0.17677669529663687f;  // 1/sqrt(32)
   float s[8];
   float mx = -INFINITY;
@@ -45,12 +53,14 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
   for (int j = 0; j < 8; ++j) {
     s[j] = -INFINITY;
     if (j < S) {
-      const T* kp = qkv + (m * S + j) * ld + W + h * D;
+      const T* kp = krow(j);
       float d = 0.f;
 #pragma unroll
-      for (int c = 0; c < D; c += 4) {
-        const float4 v = load4(kp + c);
-        d = fmaf(q[c], v.x, d); d = fmaf(q[c + 1], v.y, d); d = fmaf(q[c + 2], v.z, d); d = fmaf(q[c + 3], v.w, d);
+      for (int c = 0; c < D; c += 8) {
+        float v[8];
+        ld8(kp + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = __builtin_fmaf(q[c + e], v[e], d);
       }
       s[j] = d * scale;
       mx = fmaxf(mx, s[j]);
@@ -63,42 +73,61 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
     l += s[j];
   }
   const float inv = 1.0f / l;
-  float o[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) o[c] = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j < S) {
-      const T* vp = qkv + (m * S + j) * ld + 2 * W + h * D;
+      const T* vp = vrow(j);
       const float pj = s[j] * inv;
 #pragma unroll
-      for (int c = 0; c < D; c += 4) {
-        const float4 v = load4(vp + c);
-        o[c] = fmaf(pj, v.x, o[c]); o[c + 1] = fmaf(pj, v.y, o[c + 1]);
-        o[c + 2] = fmaf(pj, v.z, o[c + 2]); o[c + 3] = fmaf(pj, v.w, o[c + 3]);
+      for (int c = 0; c < D; c += 8) {
+        float v[8];
+        ld8(vp + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[c + e] = __builtin_fmaf(pj, v[e], o[c + e]);
       }
     }
   }
-  if (out8) {   // precision "fp8": the consumer GEMM (out_proj) takes e4m3 activations
+}
+
+template <typename T>
+__device__ __forceinline__ void vit_store_head(const float (&o)[32], T* op, uint8_t* o8p, float inv8) {
+  constexpr int D = 32;
+  if (o8p) {   // precision "fp8": the consumer GEMM (out_proj) takes e4m3 activations
     uint32_t w[8];
 #pragma unroll
     for (int c = 0; c < D; c += 4) w[c >> 2] = pack4_fp8(make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]), inv8);
-    uint4* o8 = reinterpret_cast<uint4*>(out8 + mi * W + h * D);
+    uint4* o8 = reinterpret_cast<uint4*>(o8p);
     o8[0] = make_uint4(w[0], w[1], w[2], w[3]);
     o8[1] = make_uint4(w[4], w[5], w[6], w[7]);
     return;
   }
-  T* op = out + mi * W + h * D;
 #pragma unroll
   for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, long long total,
+                                                        int S, int W, int heads, uint8_t* out8 = nullptr, float inv8 = 1.0f) {
+  constexpr int D = 32;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int h = (int)(idx % heads);
+  const long long mi = idx / heads;       // m * S + i
+  const long long m = mi / S;
+  const int ld = 3 * W;
+  float o[D];
+  vit_head_attention<T>(qkv + mi * ld + h * D, S, [&](int j) { return qkv + (m * S + j) * ld + W + h * D; },
+                        [&](int j) { return qkv + (m * S + j) * ld + 2 * W + h * D; }, o);
+  vit_store_head<T>(o, out + mi * W + h * D, out8 ? out8 + mi * W + h * D : nullptr, inv8);
 }
 
 // The same attention for the hot shape (bf16, 5 tokens, width 768, 24 heads) with the operands staged in LDS. In the kernel above every
 // (query, head) thread re-reads its crop's K and V rows itself: 84 KB per crop go through the vector L1 in 8-byte requests for 23 KB
 // of HBM data (4.2 TB/s). Here a workgroup copies the contiguous q|k|v rows of TWO crops (10 x 4 608 B) into LDS once with 16-byte
 // LDS-DMA requests and its 240 (crop, query, head) threads read them from there with ds_read_b128; three workgroups per CU keep
-// 135 KB of loads in flight. The arithmetic (order of every fma, expf, the normalisation) is the kernel above's: results are
-// bit-identical.
+// 135 KB of loads in flight (5.4 TB/s). Same per-head body as the other two kernels: bit-identical results.
 constexpr int VA_S = 5, VA_W = 768, VA_H = 24, VA_ROWB = 3 * VA_W * 2;   // bytes per qkv row
 __global__ __launch_bounds__(256) void vit_attn_lds_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int M,
                                                             uint8_t* out8, float inv8) {
@@ -120,73 +149,12 @@ __global__ __launch_bounds__(256) void vit_attn_lds_kernel(const bf16_t* __restr
   if (tid >= nc * VA_S * VA_H) return;
   const int cl = tid / (VA_S * VA_H), rem = tid % (VA_S * VA_H);
   const int i = rem / VA_H, h = rem % VA_H;
-  const char* base = va_smem + cl * VA_S * VA_ROWB;
-  auto ld8 = [](const char* p, float* f) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
-  };
-  float q[D];
-#pragma unroll
-  for (int c = 0; c < D; c += 8) ld8(base + i * VA_ROWB + h * (D * 2) + c * 2, q + c);
-  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
-  float s[VA_S];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < VA_S; ++j) {
-    const char* kp = base + j * VA_ROWB + VA_W * 2 + h * (D * 2);
-    float d = 0.f;
-#pragma unroll
-    for (int c = 0; c < D; c += 8) {
-      float v[8];
-      ld8(kp + c * 2, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d = fmaf(q[c + e], v[e], d);
-    }
-    s[j] = d * scale;
-    mx = fmaxf(mx, s[j]);
-  }
-  float l = 0.f;
-#pragma unroll
-  for (int j = 0; j < VA_S; ++j) {
-    s[j] = expf(s[j] - mx);
-    l += s[j];
-  }
-  const float inv = 1.0f / l;
+  const bf16_t* base = reinterpret_cast<const bf16_t*>(va_smem) + cl * VA_S * (3 * VA_W);
   float o[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) o[c] = 0.f;
-#pragma unroll
-  for (int j = 0; j < VA_S; ++j) {
-    const char* vp = base + j * VA_ROWB + 2 * VA_W * 2 + h * (D * 2);
-    const float pj = s[j] * inv;
-#pragma unroll
-    for (int c = 0; c < D; c += 8) {
-      float v[8];
-      ld8(vp + c * 2, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[c + e] = fmaf(pj, v[e], o[c + e]);
-    }
-  }
+  vit_head_attention<bf16_t>(base + i * (3 * VA_W) + h * D, VA_S, [&](int j) { return base + j * (3 * VA_W) + VA_W + h * D; },
+                             [&](int j) { return base + j * (3 * VA_W) + 2 * VA_W + h * D; }, o);
   const long long mi = (m0 + cl) * VA_S + i;
-  if (out8) {
-    uint32_t w8[8];
-#pragma unroll
-    for (int c = 0; c < D; c += 4) w8[c >> 2] = pack4_fp8(make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]), inv8);
-    uint4* o8 = reinterpret_cast<uint4*>(out8 + mi * VA_W + h * D);
-    o8[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
-    o8[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
-    return;
-  }
-  uint4* op = reinterpret_cast<uint4*>(out + mi * VA_W + h * D);
-#pragma unroll
-  for (int c = 0; c < D; c += 8) {
-    uint4 u;
-    u.x = pack2_bf16(o[c], o[c + 1]); u.y = pack2_bf16(o[c + 2], o[c + 3]); u.z = pack2_bf16(o[c + 4], o[c + 5]); u.w = pack2_bf16(o[c + 6], o[c + 7]);
-    op[c >> 3] = u;
-  }
+  vit_store_head<bf16_t>(o, out + mi * VA_W + h * D, out8 ? out8 + mi * VA_W + h * D : nullptr, inv8);
 }
 
 // Last ViT block: only the cls token (token 0) is read by ln_post (vit.py:186), so only its query is needed.
@@ -201,66 +169,10 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
   const int h = (int)(idx % heads);
   const long long m = idx / heads;
   const int ld = 2 * W;
-  const T* qp = qb + m * W + h * D;
-  float q[D];
-#pragma unroll
-  for (int c = 0; c < D; c += 4) {
-    const float4 v = load4(qp + c);
-    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
-  }
-  const float scale = 0.17677669529663687f;
-  float s[8];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    s[j] = -INFINITY;
-    if (j < S) {
-      const T* kp = kv + (m * S + j) * ld + h * D;
-      float d = 0.f;
-#pragma unroll
-      for (int c = 0; c < D; c += 4) {
-        const float4 v = load4(kp + c);
-        d = fmaf(q[c], v.x, d); d = fmaf(q[c + 1], v.y, d); d = fmaf(q[c + 2], v.z, d); d = fmaf(q[c + 3], v.w, d);
-      }
-      s[j] = d * scale;
-      mx = fmaxf(mx, s[j]);
-    }
-  }
-  float l = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    s[j] = j < S ? expf(s[j] - mx) : 0.f;
-    l += s[j];
-  }
-  const float inv = 1.0f / l;
   float o[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) o[c] = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < S) {
-      const T* vp = kv + (m * S + j) * ld + W + h * D;
-      const float pj = s[j] * inv;
-#pragma unroll
-      for (int c = 0; c < D; c += 4) {
-        const float4 v = load4(vp + c);
-        o[c] = fmaf(pj, v.x, o[c]); o[c + 1] = fmaf(pj, v.y, o[c + 1]);
-        o[c + 2] = fmaf(pj, v.z, o[c + 2]); o[c + 3] = fmaf(pj, v.w, o[c + 3]);
-      }
-    }
-  }
-  if (out8) {
-    uint32_t w[8];
-#pragma unroll
-    for (int c = 0; c < D; c += 4) w[c >> 2] = pack4_fp8(make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]), inv8);
-    uint4* o8 = reinterpret_cast<uint4*>(out8 + m * W + h * D);
-    o8[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    o8[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    return;
-  }
-  T* op = out + m * W + h * D;
-#pragma unroll
-  for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
+  vit_head_attention<T>(qb + m * W + h * D, S, [&](int j) { return kv + (m * S + j) * ld + h * D; },
+                        [&](int j) { return kv + (m * S + j) * ld + W + h * D; }, o);
+  vit_store_head<T>(o, out + m * W + h * D, out8 ? out8 + m * W + h * D : nullptr, inv8);
 }
 
 // =============================================================================================== generic exact kernel
@@ -510,6 +422,14 @@ __device__ __forceinline__ uint2 lds_read_tr16(const char* lds_ptr) {
   return __builtin_bit_cast(uint2, v);
 }
 
+// LDS-DMA (16 bytes per lane straight from global memory into LDS at M0 + lane * 16), SADDR form: wave-uniform 64-bit base in SGPRs +
+// per-lane unsigned 32-bit byte offset. Inline asm: hipcc's wait-count pass does not see it, the kernel counts vmcnt itself.
+__device__ __forceinline__ void attn_glds16(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
 template <int D>
 __device__ __forceinline__ int kswz(int r, int c) {
   if (D == 64) return c ^ ((r >> 1) & 7);   // 128-B rows, 8 chunks
@@ -527,13 +447,18 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   constexpr int ROWB = D * 2;
   constexpr int KS_BYTES = 64 * ROWB;
   constexpr int VT_BYTES = D * VT4_STRIDE * 2;
-  constexpr int CH = 64 * CPR / 256;                          // chunks per thread per tile (2 for D=64, 1 for D=32)
-  char* ks_base = smem4;                                       // [2][64][ROWB]
-  char* vt_base = smem4 + 2 * KS_BYTES;                               // [2] x V image (sub-tiled, see vsub_off)
-  float* madd = reinterpret_cast<float*>(smem4 + 2 * KS_BYTES + 2 * VT_BYTES);   // [nt*64]
+  // K / V tiles are staged by LDS-DMA into a ring of NSTG stages; NSTG - 1 tiles are in flight while one is multiplied. (Round 3:
+  // the register-staged double buffer spent 18 % of a key tile issuing the next tile's loads -- address arithmetic and four 16-byte
+  // loads per lane -- and 8 % writing them to LDS; per-phase shader-clock stamps, scripts/attn_micro.py STAMPS=1.)
+  constexpr int NSTG = QG > 1 ? 3 : 2;                         // 64 queries per wave run two workgroups per CU: room for three stages
+  constexpr int NI = D / 32;                                   // 1-KiB DMA instructions per wave and tile for K, and as many for V
+  char* ks_base = smem4;                                       // [NSTG][64][ROWB]
+  char* vt_base = smem4 + NSTG * KS_BYTES;                            // [NSTG] x V image (sub-tiled, see vsub_off)
+  float* madd = reinterpret_cast<float*>(smem4 + NSTG * KS_BYTES + NSTG * VT_BYTES);   // [nt*64]
   const int nt = (p.Lk + 63) / 64;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform (LDS-DMA destinations live in SGPRs / M0)
   const int hi = lane >> 5, l31 = lane & 31;
   // XCD-aware order (workgroup id % 8 = XCD): the query blocks of one (batch, head) run back to back on ONE XCD so its
   // K/V (re-read by every query block) stay in that XCD's L2: id = ((bh / 8) * nq + qblk) * 8 + bh % 8
@@ -602,44 +527,54 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   // keys 4 hi + i/4 (i = lane&15; hi = g>>1), 8-byte column quad i%4. The k-slots of the P^T operand are the S^T
   // accumulator registers: lane-half hi holds keys 4hi+{0..3} and 8+4hi+{0..3} of each 16-key step.
   const int vlane = vsub_off((lane >> 4) & 1) + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
-  // staging registers of the next tile (named scalars, not arrays: hipcc kept `uint4 kreg[CH]` in scratch memory, which
-  // forced a vmcnt(0) + scratch round trip right behind every global load and exposed its full latency every tile)
-  uint4 kreg0, kreg1, vreg0, vreg1;
-  // running per-thread pointers to this thread's chunk(s) of the CURRENT tile; a tile step is 64 rows. Only a ragged last
-  // tile needs the row clamp (64-bit multiplies per load otherwise cost ~15 % of the loop in address arithmetic).
-  const int key0 = tid / CPR, ch0 = tid % CPR;
-  const int key1 = (tid + 256) / CPR, ch1 = (tid + 256) % CPR;
+  // DMA geometry. K: instruction j = w * NI + i fills LDS chunks p = j * 64 + lane of the [64 keys][CPR chunks] image, i.e. key
+  // p / CPR at swizzled position p % CPR, which holds the row's chunk (p % CPR) ^ swizzle(key): the XOR moves to the GLOBAL side.
+  // V: instruction j fills half (j & 1) of sub-tile j / 2 ([64 keys][16 d], 32-byte rows): lane -> key 32 (j & 1) + lane / 2,
+  // 16-byte part lane & 1 of the row's 32-byte segment 2 (j / 2) + part. Per-lane byte offsets inside a tile are fixed; the tile's
+  // first row is a wave-uniform pointer (SGPRs), so a tile costs no vector address arithmetic.
   const bf16_t* Kb = K + (long long)b * p.Lkr * p.ldk + h * D;
   const bf16_t* Vb = V + (long long)b * p.Lkr * p.ldv + h * D;
-  auto gload = [&](int t) {
-    int r0 = t * 64 + key0, r1 = t * 64 + key1;
-    if ((t + 1) * 64 > p.Lk) {   // workgroup-uniform: ragged last tile
-      r0 = r0 < p.Lk ? r0 : p.Lk - 1;
-      r1 = r1 < p.Lk ? r1 : p.Lk - 1;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem4;
+  auto k_key = [&](int i) { return ((w * NI + i) * 64 + lane) / CPR; };
+  auto k_chunk = [&](int i) { const int pp = ((w * NI + i) * 64 + lane) % CPR; return kswz<D>(k_key(i), pp); };
+  auto v_key = [&](int i) { return ((w * NI + i) & 1) * 32 + (lane >> 1); };
+  auto v_chunk = [&](int i) { return 2 * ((w * NI + i) >> 1) + (lane & 1); };
+  const unsigned kvo0 = (unsigned)(k_key(0) * p.ldk * 2 + k_chunk(0) * 16), vvo0 = (unsigned)(v_key(0) * p.ldv * 2 + v_chunk(0) * 16);
+  const unsigned kvo1 = NI > 1 ? (unsigned)(k_key(NI - 1) * p.ldk * 2 + k_chunk(NI - 1) * 16) : 0u;
+  const unsigned vvo1 = NI > 1 ? (unsigned)(v_key(NI - 1) * p.ldv * 2 + v_chunk(NI - 1) * 16) : 0u;
+  auto dma_tile = [&](int t, int stg) {
+    const char* kt = reinterpret_cast<const char*>(Kb + (long long)t * 64 * p.ldk);
+    const char* vtp = reinterpret_cast<const char*>(Vb + (long long)t * 64 * p.ldv);
+    const unsigned kl = lds0 + stg * KS_BYTES + (w * NI) * 1024;
+    const unsigned vl = lds0 + NSTG * KS_BYTES + stg * VT_BYTES;
+    unsigned ko0 = kvo0, ko1 = kvo1, vo0 = vvo0, vo1 = vvo1;
+    if ((t + 1) * 64 > p.Lk) {   // workgroup-uniform: ragged last tile -> rows beyond Lk re-read the last key (masked by madd = -inf)
+      const int last = p.Lk - 1 - t * 64;
+      auto cl = [&](int key) { return key < last ? key : last; };
+      ko0 = (unsigned)(cl(k_key(0)) * p.ldk * 2 + k_chunk(0) * 16); vo0 = (unsigned)(cl(v_key(0)) * p.ldv * 2 + v_chunk(0) * 16);
+      if (NI > 1) {
+        ko1 = (unsigned)(cl(k_key(NI - 1)) * p.ldk * 2 + k_chunk(NI - 1) * 16); vo1 = (unsigned)(cl(v_key(NI - 1)) * p.ldv * 2 + v_chunk(NI - 1) * 16);
+      }
     }
-    kreg0 = *reinterpret_cast<const uint4*>(Kb + (long long)r0 * p.ldk + ch0 * 8);
-    vreg0 = *reinterpret_cast<const uint4*>(Vb + (long long)r0 * p.ldv + ch0 * 8);
-    if constexpr (CH > 1) {
-      kreg1 = *reinterpret_cast<const uint4*>(Kb + (long long)r1 * p.ldk + ch1 * 8);
-      vreg1 = *reinterpret_cast<const uint4*>(Vb + (long long)r1 * p.ldv + ch1 * 8);
+    attn_glds16(kt, ko0, kl);
+    attn_glds16(vtp, vo0, vl + vsub_off((w * NI) >> 1) + ((w * NI) & 1) * 1024);
+    if (NI > 1) {
+      attn_glds16(kt, ko1, kl + 1024);
+      attn_glds16(vtp, vo1, vl + vsub_off((w * NI + 1) >> 1) + ((w * NI + 1) & 1) * 1024);
     }
   };
-  auto lstore1 = [&](int buf, int i, const uint4& kr, const uint4& vr) {
-    char* ks = ks_base + buf * KS_BYTES;
-    char* vt = vt_base + buf * VT_BYTES;
-    const int id = tid + i * 256;
-    const int key = id / CPR, c = id % CPR;
-    *reinterpret_cast<uint4*>(ks + key * ROWB + (kswz<D>(key, c) << 4)) = kr;
-    *reinterpret_cast<uint4*>(vt + vsub_off(c >> 1) + key * 32 + (c & 1) * 16) = vr;
+  // `younger` tiles of this wave's DMA may stay in flight (VMEM retires in order; 2 NI instructions per tile); then the workgroup
+  // barrier: every wave's share of the awaited tile has landed and nobody still reads the stage that is refilled next
+  auto wait_tile_and_barrier = [&](int younger) {
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NI) : "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS reads / writes are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
-  auto lstore = [&](int buf) {
-    lstore1(buf, 0, kreg0, vreg0);
-    if constexpr (CH > 1) lstore1(buf, 1, kreg1, vreg1);
-  };
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  dma_tile(0, 0);   // (the ring is disjoint from the tables; tflag becomes visible with the barrier below)
+  if (NSTG > 2 && nt > 1) dma_tile(1, 1);
+  wait_tile_and_barrier(NSTG > 2 && nt > 1 ? 1 : 0);
   // The query fragments were requested above with plain global loads. hipcc's wait-count pass carries "these loads may
   // still be pending" into the key-tile loop (it cannot know they landed during the first iteration) and therefore put
   // `s_waitcnt vmcnt(3..0)` in front of the first S^T MFMAs of EVERY iteration -- right behind the prefetch loads of the next
@@ -665,12 +600,12 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     }
   };
 
+  int stg = 0, stg_in = NSTG - 1;                             // stage of tile t / of the tile requested in iteration t
   for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) gload(t + 1);                              // in flight while this tile is multiplied
-    mark(0);   // global loads of the next tile issued
-    const char* ks = ks_base + buf * KS_BYTES;
-    const char* vt = vt_base + buf * VT_BYTES + vlane;
+    if (t + NSTG - 1 < nt) dma_tile(t + NSTG - 1, stg_in);     // into the stage read in iteration t - 1 (all waves are past its barrier)
+    mark(0);   // DMA of tile t + NSTG - 1 issued
+    const char* ks = ks_base + stg * KS_BYTES;
+    const char* vt = vt_base + stg * VT_BYTES + vlane;
     const int k0 = t * 64;
     // ---- S^T for the two 32-key sub-tiles (alternating the two accumulators per k-step measured 7 % slower); every K
     // fragment is read once and multiplied with the queries of all QG groups
@@ -789,10 +724,14 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
         }
       }
     mark(3);   // PV MFMAs issued
-    if (t + 1 < nt) lstore(buf ^ 1);
-    mark(4);   // next tile written to LDS (waits for its global loads)
-    __syncthreads();
-    mark(5);   // barrier
+    {
+      int last = t + NSTG - 1;                                 // tiles requested so far: up to min(nt - 1, t + NSTG - 1)
+      last = last < nt - 1 ? last : nt - 1;
+      wait_tile_and_barrier(last - (t + 1));
+    }
+    mark(5);   // tile t + 1 landed, barrier
+    stg = stg + 1 == NSTG ? 0 : stg + 1;
+    stg_in = stg_in + 1 == NSTG ? 0 : stg_in + 1;
   }
   if (dbg && tid == 0) {
 #pragma unroll
@@ -1132,15 +1071,15 @@ template <int D, int MODE, int QG>
 static int launch_mfma4_qg(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   const int nt = (a.Lk + 63) / 64;
   const int nq = (a.Lq + 128 * QG - 1) / (128 * QG);
-  const size_t sh = 2 * (64 * D * 2) + 2 * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 + (size_t)((nt + 3) & ~3) * 4 +
+  constexpr int NSTG = QG > 1 ? 3 : 2;   // as in the kernel
+  const size_t sh = NSTG * (64 * D * 2) + NSTG * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 + (size_t)((nt + 3) & ~3) * 4 +
                     (MODE == ATTN_T5 ? (size_t)(nq * 128 * QG + nt * 64) * 4 : 0);
   if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma4_kernel<D, MODE, QG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma4_kernel<D, MODE, QG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   const int bh8 = (a.B * a.H + 7) / 8;
   dim3 grid((unsigned)(bh8 * 8 * nq), 1, 1);
@@ -1166,12 +1105,11 @@ static int launch_split(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   const size_t comb = (size_t)4 * (D / 32 * 16 + 2) * 64 * 4;
   if (sh < comb) sh = comb;
   if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel<D, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel<D, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   hipLaunchKernelGGL((attn_split_kernel<D, MODE>), dim3((unsigned)(((a.B * a.H + 15) / 16) * 16)), dim3(256), sh, st, d);
   return (int)hipGetLastError();

@@ -14,6 +14,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int kWave = 64;
 
+// hipFuncSetAttribute (the dynamic-LDS limit of a kernel) applies to the CURRENT device only: every launcher that raises the limit
+// keeps one of these per kernel instantiation and asks it before launching, so that a process driving several GPUs (or a handle
+// created on a device other than the first one used) gets the attribute on each of them.
+struct PerDeviceOnce {
+  unsigned long long done = 0;   // bit d: attribute set on device d (devices >= 64 are simply set every time)
+  // returns hipSuccess when the attribute is (now) set on the current device
+  template <typename F> hipError_t ensure(F&& set_attribute) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return hipSuccess;
+    e = set_attribute();
+    if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
+    return e;
+  }
+};
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even; lowers to the gfx950 hardware conversion (v_cvt_pk_bf16_f32)

@@ -1626,12 +1626,11 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 
 template <typename T, typename TL, int ACT, bool VEC, bool ASMLDS, bool W8 = false>
 int launch_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TL, ACT, VEC, ASMLDS, W8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM_ALLOC);
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TL, ACT, VEC, ASMLDS, W8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM_ALLOC); });
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   hipLaunchKernelGGL((gemm_kernel<T, TL, ACT, VEC, ASMLDS, W8>), grid, dim3(TL::THREADS), TL::SMEM_ALLOC, st, d);
   return (int)hipGetLastError();
@@ -1681,12 +1680,11 @@ int g_num_cu = 0;
 template <int ACT, int EPI, bool W8>
 int launch_persistent_w(const GemmDev& d, int grid, hipStream_t st) {
   constexpr int SMEM = TileL::SMEM_BYTES + TileL::NW * 4096;   // ring + epilogue slabs = 160 KiB
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT, EPI, W8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<ACT, EPI, W8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   hipLaunchKernelGGL((gemm_persistent_kernel<ACT, EPI, W8>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
   return (int)hipGetLastError();
@@ -1736,12 +1734,11 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
 template <int ACT, int EPI, bool F8>
 int launch_pp_inst2(const GemmDev& d, int grid, hipStream_t st) {
   constexpr int SMEM = 8 * 16384 + TileL::NW * 4096;   // eight half-tile slots + epilogue slabs = 160 KiB
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<ACT, EPI, F8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<ACT, EPI, F8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   hipLaunchKernelGGL((gemm_pp_kernel<ACT, EPI, F8>), dim3((unsigned)grid), dim3(TileL::THREADS), SMEM, st, d);
   return (int)hipGetLastError();
@@ -1808,12 +1805,11 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
 
 template <int ACT, int EPI>
 int launch_wide_inst(const GemmDev& d, int grid, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<ACT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, TileW::SMEM_BYTES);
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<ACT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TileW::SMEM_BYTES); });
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   hipLaunchKernelGGL((gemm_wide_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(TileW::THREADS), TileW::SMEM_BYTES, st, d);
   return (int)hipGetLastError();

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <string>
 
+#include "common.h"   // PerDeviceOnce
+
 namespace vima {
 int api_fail(const std::string& m);
 }
@@ -234,13 +236,27 @@ extern "C" int vima_crop_objects(const uint8_t* rgb, const void* segm, int segm_
   hipStream_t st = (hipStream_t)stream;
   long long need = 3LL * H * W;
   const int lds = (int)(need < 96 * 1024 ? need : 96 * 1024);   // a whole 128 x 256 frame fits; larger frames: crops up to 96 KiB
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_objects_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_objects_kernel<int>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-      return vima::api_fail("vima_crop_objects: hipFuncSetAttribute failed");
-    attr_done = true;
+  // the launch goes to the device that owns the output tensors (not necessarily the current one: the call has no handle)
+  int cur_dev = 0, out_dev = 0;
+  hipPointerAttribute_t pa;
+  if (hipGetDevice(&cur_dev) != hipSuccess) return vima::api_fail("vima_crop_objects: hipGetDevice failed");
+  out_dev = cur_dev;
+  if (hipPointerGetAttributes(&pa, crops) == hipSuccess) out_dev = pa.device;
+  struct DeviceGuard {
+    int back; bool active;
+    ~DeviceGuard() { if (active) (void)hipSetDevice(back); }
+  } guard{cur_dev, false};
+  if (out_dev != cur_dev) {
+    if (hipSetDevice(out_dev) != hipSuccess) return vima::api_fail("vima_crop_objects: hipSetDevice failed");
+    guard.active = true;
   }
+  static vima::PerDeviceOnce attr;
+  if (attr.ensure([&] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_objects_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_objects_kernel<int>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      }) != hipSuccess)
+    return vima::api_fail("vima_crop_objects: hipFuncSetAttribute failed");
   if (segm_elem_bytes == 1)
     hipLaunchKernelGGL(crop_objects_kernel<uint8_t>, dim3((unsigned)n_frames, (unsigned)n_obj), dim3(256), (size_t)lds, st, rgb, (const uint8_t*)segm, obj_ids,
                        n_obj, H, W, crops, (long long*)bbox, mask, lds);

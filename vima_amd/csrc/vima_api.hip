@@ -2021,7 +2021,14 @@ int vima_seq_decode(VimaHandle* h, const float* obs_tok, const float* act_tok, i
   if (T <= 0 || B <= 0 || Lp <= 0) return fail("vima_seq_decode: empty input");
   if (L_act < 0 || L_act > T || (L_act > 0 && !act_tok) || L_act < T - 1) return fail("vima_seq_decode: L_act must be T-1 or T");
   const int L = Lp + 1 + T * Q + L_act;
-  if (L > h->cfg.n_positions)   // positions_embed lookup beyond the table (gpt/gpt.py:177-185 raises IndexError)
+  // The bound is on the PADDED length L, like the reference's: its position ids only reach max_b(valid prompt tokens) + 1 + T*Q +
+  // L_act - 1 (vima_gato_policy.py:156-184), but the causal-mask buffer of the HF OpenAI-GPT attention is [n_positions, n_positions]
+  // and is cropped to it (`b = self.bias[:, :, : w.size(-2), : w.size(-1)]`; `w * b` then fails to broadcast for L > n_positions),
+  // so a padded batch longer than the table does not run there either. One deviation is deliberate: a sample whose prompt mask is
+  // ALL false gets position id 0 for its padding (seq_embed_kernel clamps), where the reference's embedding lookup raises
+  // IndexError for the id -1 it builds (torch.arange(0) ++ fill_(n_valids - 1)); the mask lives on the device and this call is
+  // asynchronous, so the host mirror (vima_amd/baselines.py) is the place that can refuse such a batch before calling.
+  if (L > h->cfg.n_positions)   // (also the positions_embed lookup beyond the table, gpt/gpt.py:177-185)
     return fail("vima_seq_decode: sequence of " + std::to_string(L) + " tokens exceeds n_positions " + std::to_string(h->cfg.n_positions), 34);
   Run R{h, (hipStream_t)stream};
   const int rq = B * L;
