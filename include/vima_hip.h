@@ -242,7 +242,7 @@ int vima_t5_bucket(int relative_position);
  *   kernel selection, attention: "attn_impl" [1] 1 MFMA flash kernels, 0 exact generic kernel
  *                            "attn_split"   [1] split-key 4-wave kernel for <= 32 queries
  *                            "attn4_min_lq" [64] query count from which the 4-wave LDS-shared flash kernel is used
- *                            "attn_qg"      [2] 32-query groups per wave in that kernel (2 from 256 queries on)
+ *                            "attn_qg"      [1] 32-query groups per wave in that kernel (2: 64 queries per wave from 256 queries on)
  *   numerics / fusion:       "stream_T"     [1] T5 / ViT residual streams carried in the operand type (see VimaConfig)
  *                            "t5_fuse_rms"  [1] T5 RMSNorms folded into the neighbouring GEMMs
  *                            "vit_prune_last" [1] last ViT block evaluated for the cls row only (identical values)

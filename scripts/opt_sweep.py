@@ -12,7 +12,7 @@ from vima_amd import synthetic as syn  # noqa: E402
 from vima_amd.policy import VIMAPolicy  # noqa: E402
 
 DEFAULTS = {"gemm_tile": 0, "stream_T": 1, "dual_stream": 1, "gemm_persist": 1, "t5_fuse_rms": 1, "vit_chunk": 16384, "gemm_splitk": 0,
-            "gemm_small": 1, "attn_qg": 2}
+            "gemm_small": 1, "attn_qg": 1}
 
 
 def main():

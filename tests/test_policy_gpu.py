@@ -146,7 +146,7 @@ def test_bf16_argmax_agreement_o1_logits_live_oracle():
 
 
 
-@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 1}, {"gemm_wide": 1}, {"gemm_pp": 0}, {"graphs": 1},
+@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 2}, {"gemm_wide": 1}, {"gemm_pp": 0}, {"graphs": 1},
                                   {"dual_stream": 0}, {"attn_split": 0}, {"gemm_epi": 0}, {"vit_prune_last": 0}])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_every_option_matches_reference_golden(opts, prec, golden_dir):
@@ -166,7 +166,7 @@ def test_every_option_matches_reference_golden(opts, prec, golden_dir):
         assert max_rel(out["prompt_tokens"].cpu(), tok) < (2e-4 if prec == "fp32" else 4e-2)
     finally:
         for k in opts:                                         # (options are per handle; restoring is belt and braces)
-            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 2, "gemm_wide": 0, "gemm_pp": 1, "graphs": 0, "dual_stream": 1,
+            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 1, "gemm_wide": 0, "gemm_pp": 1, "graphs": 0, "dual_stream": 1,
                                "attn_split": 1, "gemm_epi": 1, "vit_prune_last": 1}[k])
 
 

@@ -437,7 +437,7 @@ __device__ __forceinline__ int kswz(int r, int c) {
 }
 
 // (phase ablations of this kernel -- timing only, wrong results -- live in scripts/ablate/attn_ablate.patch)
-// QG = query groups of 32 per wave. QG = 2 (opt-in, option attn_qg): a wave owns 64 queries, i.e. a workgroup 256; every K / V
+// QG = query groups of 32 per wave. QG = 2 (option attn_qg = 2): a wave owns 64 queries, i.e. a workgroup 256; every K / V
 // fragment read from LDS feeds TWO MFMAs (one per group), and the staging of a key tile (global loads, LDS stores, barrier) is
 // amortised over twice the queries; the softmax VALU work per query is unchanged. Costs registers (two waves per SIMD).
 template <int D, int MODE, int QG = 1>
@@ -1088,10 +1088,11 @@ static int launch_mfma4_qg(const AttnDev& d, const AttnArgs& a, hipStream_t st) 
 }
 template <int D, int MODE>
 static int launch_mfma4(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
-  // 64 queries per wave from 256 queries on (measured on MI355X: T5 shape 0.418 -> 0.405 ms, D = 32 cross attention 0.131 ->
-  // 0.119 ms; identical results: every query row is processed exactly as before). Not for the causal mode (its D = 64
-  // instantiation would spill). Option attn_qg = 1 keeps 32 queries per wave.
-  const int qg = (a.tune && a.tune->attn_qg > 0) ? a.tune->attn_qg : 2;
+  // Option attn_qg = 2: 64 queries per wave from 256 queries on (identical results: every query row is processed exactly as
+  // before; not for the causal mode, whose D = 64 instantiation would spill). It was the default in round 2 (register-staged K / V:
+  // T5 shape 0.418 -> 0.405 ms); with the LDS-DMA ring 32 queries per wave (three workgroups per CU) are 3-4 % faster at the T5 shape
+  // on every box measured (0.364 / 0.379, 0.379 / 0.392, 0.388 / 0.398 ms; L = 1024: 1.237 / 1.265 ms) and equal at D = 32.
+  const int qg = (a.tune && a.tune->attn_qg > 0) ? a.tune->attn_qg : 1;
   if constexpr (MODE != ATTN_CAUSAL) {
     if (qg == 2 && a.Lq >= 256) return launch_mfma4_qg<D, MODE, 2>(d, a, st);
   }
