@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-P='import sys,json; d=json.loads(sys.stdin.read()); c=d["config"]; print(sys.argv[1], "cold ms", d["ms_per_step"], "warm ms", c["warm_ms_per_step"], "incremental ms", c.get("incremental_env_step_ms"))'
-for G in 0 1; do
-for B in 1 32 256; do
-timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --batch $B --opt graphs=$G 2>&1 | tail -1 | python -c "$P" "200M B$B graphs=$G:"
+for g in 0 1; do
+  timeout 300 python scripts/warm_steps.py warm 20 256 graphs=$g 2>&1 | tail -1
 done
+for g in 0 1; do
+  timeout 300 python scripts/warm_steps.py inc 16 256 graphs=$g 2>&1 | tail -1
 done
