@@ -65,6 +65,10 @@ typedef struct VimaConfig {
 int vima_create(const VimaConfig* cfg, int device, VimaHandle** out);
 void vima_destroy(VimaHandle* h);
 const char* vima_last_error(void);
+/* 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w; 3: + VimaConfig.policy_kind and the
+ * baseline-policy entry points; 4: + VIMA_PRECISION_FP8, vima_fp8_act_scales, vima_decode_restart, vima_prof_read_gemm_kernels.
+ * The ONE place the number lives: the library returns it, the ctypes binding parses it from this header and refuses a mismatch. */
+#define VIMA_ABI_VERSION 4
 int vima_abi_version(void);
 
 /* ---- weights: the reference checkpoint contract -------------------------------------------------------------- */

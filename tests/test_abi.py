@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/vima_hip.h but not exported by libvima_hip.so"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert lib.vima_abi_version() == 4
+    assert lib.vima_abi_version() == _lib.ABI_VERSION == 4   # single source: VIMA_ABI_VERSION in include/vima_hip.h
 
 
 def test_t5_bucket_matches_oracle():

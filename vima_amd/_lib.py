@@ -22,6 +22,18 @@ class VimaConfig(ctypes.Structure):
                                      "xattn_n_positions", "n_positions", "precision", "policy_kind")]
 
 
+def _header_abi_version() -> int:
+    """VIMA_ABI_VERSION of include/vima_hip.h (the one place the number lives); the header ships with the package's repository."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "vima_hip.h")
+    with open(hdr) as f:
+        m = re.search(r"^#define\s+VIMA_ABI_VERSION\s+(\d+)", f.read(), flags=re.M)
+    if not m:
+        raise RuntimeError(f"VIMA_ABI_VERSION not found in {hdr}")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
 PRECISION = {"fp32": 0, "bf16": 1, "fp8w": 2, "fp8": 3}
 POLICY_KIND = {"vima": 0, "gpt": 1, "gato": 2, "flamingo": 3}   # VIMA_POLICY_* (include/vima_hip.h)
 
@@ -98,6 +110,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.vima_abi_version() != ABI_VERSION:   # a stale build of the library against a newer header (or the reverse)
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.vima_abi_version()}, include/vima_hip.h declares {ABI_VERSION}: rebuild "
+                           "with `bash vima_amd/csrc/build.sh`")
     _lib = lib
     return lib
 

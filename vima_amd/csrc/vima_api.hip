@@ -1329,7 +1329,7 @@ int run_graphed(VimaHandle* h, std::string key, hipStream_t user, F&& fn) {
 // =================================================================================================== C ABI
 extern "C" {
 
-int vima_abi_version(void) { return 4; }   // 4: + precision fp8 (VIMA_PRECISION_FP8, vima_fp8_act_scales), vima_decode_restart, vima_prof_read_gemm_kernels ; 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w; 3: + VimaConfig.policy_kind, baseline-policy entry points
+int vima_abi_version(void) { return VIMA_ABI_VERSION; }   // include/vima_hip.h
 const char* vima_last_error(void) { return g_err.c_str(); }
 int vima_t5_bucket(int rel) { return t5_bucket(rel); }
 void vima_fp8_e4m3_encode(const float* src, uint8_t* dst, int64_t n) {
