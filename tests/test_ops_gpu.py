@@ -265,6 +265,33 @@ def test_layernorm(rows, E, rms):
     assert max_rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("rows,E,rms", [(1, 768, 0), (2, 768, 0), (7, 256, 0), (1001, 768, 0), (40961, 768, 0), (513, 512, 1), (64, 1024, 0),
+                                        (5, 320, 1), (33, 384, 0)])
+def test_layernorm_of_a_bf16_stream(rows, E, rms):
+    """The ViT / decoder LayerNorms read the residual stream in bf16 (stream_T): rows of 256 n elements take the half-wave-per-row
+    kernel (two rows per wave, odd row counts, a grid-strided walk from 16 384 rows on), other lengths the one-wave-per-row kernel;
+    both against torch on the bf16-rounded input."""
+    pol = bare_policy("bf16")
+    g = torch.Generator().manual_seed(rows * 7 + E)
+    x = bf(torch.randn(rows, E, generator=g) * 3 + 0.5)
+    ga, be = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    if rms:
+        ref = ga * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    else:
+        ref = torch.nn.functional.layer_norm(x, (E,), ga, be, 1e-5)
+    out = torch.empty(rows, E, device="cuda")
+    xd, gd, bd = x.cuda(), ga.cuda(), be.cuda()
+    pol.set_option("op_stream_T", 1)
+    try:
+        _lib.check(pol._lib.vima_op_layernorm(pol._handle, ptr(xd), ptr(gd), None if rms else ptr(bd), 1e-6 if rms else 1e-5, rms,
+                                              rows, E, ptr(out), pol._stream()))
+        torch.cuda.synchronize()
+    finally:
+        pol.set_option("op_stream_T", 0)
+    assert max_rel(out, ref) < 1e-5
+    assert torch.isfinite(out).all()
+
+
 def attn_ref(q, k, v, kmask, relbias, scale, mode):
     """Literal restatement of the three score pipelines (prompt_encoder.py:769-801, components.py:184-207, :54-69)."""
     B, Lq, H, D = q.shape
@@ -321,6 +348,41 @@ def test_attention(prec, impl, mode, B, H, Lq, Lk, D):
     # bf16: probabilities and outputs are rounded to bf16 (2^-9 relative each)
     assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)
 
+
+@pytest.mark.parametrize("mode,B,H,Lq,Lk,D", [(0, 1, 12, 300, 300, 64), (0, 2, 3, 1030, 1030, 64), (1, 2, 24, 300, 520, 32), (1, 1, 4, 256, 64, 64),
+                                             (0, 1, 2, 257, 257, 32)])
+@pytest.mark.parametrize("qg", [1, 2])
+def test_attention_lds_dma_ring_both_geometries(qg, mode, B, H, Lq, Lk, D):
+    """The 4-wave flash kernel stages K / V by LDS-DMA into a ring of 2 stages (32 queries per wave, default) or 3 stages (64 queries
+    per wave, option attn_qg = 2, from 256 queries on): ragged last tiles, a single tile, more tiles than stages, masked keys; the two
+    geometries process every query row with the same arithmetic, so their outputs are IDENTICAL, and both agree with torch."""
+    pol = bare_policy("bf16")
+    g = torch.Generator().manual_seed(mode * 100 + Lq + Lk)
+    sc = 1.0 if mode else 0.4
+    q = torch.randn(B, Lq, H, D, generator=g) * sc
+    k = torch.randn(B, Lk, H, D, generator=g) * sc
+    v = torch.randn(B, Lk, H, D, generator=g)
+    kmask = torch.rand(B, Lk, generator=g) > 0.2
+    kmask[:, 0] = True
+    relbias = torch.randn(H, 2 * Lk - 1, generator=g) if mode == 0 else None
+    scale = 1.0 if mode == 0 else 1.0 / math.sqrt(D)
+    ref = attn_ref(bf(q), bf(k), bf(v), kmask, relbias, scale, mode)
+    qd, kd, vd, md = q.cuda(), k.cuda(), v.cuda(), kmask.cuda()
+    rd = relbias.cuda() if relbias is not None else None
+    outs = {}
+    try:
+        for geo in (qg, 3 - qg):
+            pol.set_option("attn_qg", geo)
+            out = torch.full((B, Lq, H, D), float("nan"), device="cuda")
+            _lib.check(pol._lib.vima_op_attention(pol._handle, ptr(qd), ptr(kd), ptr(vd), ptr(md), ptr(rd), B, H, Lq, Lk, D, scale, mode,
+                                                  1, ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            outs[geo] = out.cpu()
+    finally:
+        pol.set_option("attn_qg", 1)
+    assert torch.isfinite(outs[qg]).all()
+    assert max_rel(outs[qg], ref) < 1.5e-2
+    assert torch.equal(outs[1], outs[2])
 
 
 @pytest.mark.parametrize("M,N,K,act,mode", [(16384, 768, 768, 0, "stream"), (16384, 768, 768, 0, "res32"), (16384, 2304, 128, 0, "bf16"),

@@ -179,7 +179,7 @@ struct VimaHandle {
                             // logits 1.5e-4. 0 = fp32 stream (round-1 behaviour)
   int t5_fuse_rms = 1;      // T5 RMSNorms folded into the neighbouring GEMMs (statistics in the producer epilogue, row scale in the consumer)
   int op_bf16_out = 0;      // vima_op_linear: route the result through the operand-type output (tests the T store paths)
-  int op_stream_T = 0;      // vima_op_linear: pass `res` in the operand type (resT) like the T5 / ViT residual GEMMs do
+  int op_stream_T = 0;      // vima_op_linear: pass `res` in the operand type (resT) like the T5 / ViT residual GEMMs do; vima_op_layernorm: bf16 input
   int dual_stream = 1;      // split independent work over two HIP streams so that HBM-bound kernels (norms, attention,
                             // GEMM epilogues) of one half overlap the MFMA-bound GEMM main loops of the other half
   hipStream_t aux = nullptr;
@@ -2153,6 +2153,13 @@ int vima_op_layernorm(VimaHandle* h, const float* x, const float* gamma, const f
   if (!h) return fail("null handle");
   HIPCK(hipSetDevice(h->device));
   Run R{h, (hipStream_t)stream};
+  if (h->op_stream_T && h->bf16) {   // test instrumentation: the input carried in the operand type, like the ViT / decoder streams
+    if (h->arena.reset()) return fail("workspace reset failed");
+    void* xT = R.wsT((size_t)rows * E);
+    if (R.err) return R.err;
+    OTHER(R, launch_cast(x, xT, (long long)rows * E, true, R.st), "cast");
+    return R.lnT(xT, E, gamma, beta, eps, rms, rows, E, out, nullptr);
+  }
   return R.ln(x, E, gamma, beta, eps, rms, rows, E, out, nullptr);
 }
 
