@@ -234,11 +234,15 @@ int vima_t5_bucket(int relative_position);
 /* ---- tuning / instrumentation ---------------------------------------------------------------------------------- */
 /* Per-handle options (every key vima_set_option accepts; unknown keys fail). Defaults in brackets.
  *   kernel selection, GEMM:  "gemm_variant" [1] 1 inline-asm LDS-DMA pipeline, 0 compiler-tracked builtin (128x128 tile only)
- *                            "gemm_tile"    [0] 0 auto, 1 force 128x128, 2 force 256x256, 7 force 32x64, 8 force 64x64
+ *                            "gemm_tile"    [0] 0 auto, 1 force 128x128, 2 force 256x256, 7 force 32x64, 8 force 64x64,
+ *                                               10 / 11 / 12 force the resident-K kernel's 32x32 / 64x32 / 64x64 tile
  *                            "gemm_persist" [1] large bf16 GEMMs on the persistent 256x256 kernels
  *                            "gemm_pp"      [1] ping-pong (8-phase) main loop of the persistent kernel (0: the round-2 loop)
  *                            "gemm_wide"    [0] 256x384 persistent tile where N % 384 == 0
  *                            "gemm_small"   [1] 64x64 / 32x64 tiles for grids that would leave most CUs idle
+ *                            "gemm_resident" [1] underfilled grids on gemm_resident_kernel ((almost) the whole K extent in flight, one
+ *                                               barrier per chunk of K-slices; bit-identical to the ring tiles), 0: the 4-deep ring tiles
+ *                            "gemm_res_maxwg" [256] largest grid (workgroups) gemm_resident_kernel takes for M > 32
  *                            "gemm_splitk"  [0] deterministic two-pass split-K for underfilled grids with K >= 1536
  *                            "gemm_raster"  [0] tile order of the one-tile-per-workgroup kernels: 0 XCD x n-walk, 1 XCD x
  *                                               resident n-group, 2 row-major
@@ -272,7 +276,8 @@ int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], dou
 int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]);
 /* The GEMM launches recorded since vima_prof_enable, grouped by the KERNEL the launcher chose: ids[i] = kind * 1000 +
  * (activation + 1) * 10 + epilogue, kind 1 gemm_pp_kernel<ACT, EPI>, 2 gemm_persistent_kernel<ACT, EPI>, 3 gemm_wide_kernel,
- * 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile, 8 two-pass split-K; per kernel the summed milliseconds,
+ * 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile, 8 two-pass split-K, 10..12 gemm_resident_kernel with the
+ * 32x32 / 64x32 / 64x64 tile; per kernel the summed milliseconds,
  * launches, algorithmic FLOPs and algorithmic HBM bytes. Returns the number of kernels (<= max_n) or a negative error; does
  * NOT reset the records (call it before vima_prof_read / vima_prof_read_ex). */
 int vima_prof_read_gemm_kernels(VimaHandle* h, int max_n, int32_t* ids, double* ms, int64_t* launches, double* flops, double* bytes);

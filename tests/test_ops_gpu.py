@@ -234,6 +234,46 @@ def test_small_tiles_match_128_tile_bitwise():
         pol.set_option("gemm_small", 1)
 
 
+def test_resident_kernel_matches_ring_tiles_bitwise():
+    """gemm_resident_kernel (underfilled grids: (almost) the whole K extent in flight, one barrier per chunk of K-slices) walks K
+    in the same order with the same matrix instruction as the ring tiles: every tile shape of it (gemm_tile 10 / 11 / 12 =
+    32x32 / 64x32 / 64x64, forced whatever the grid) and the launcher's own choice must be BIT-identical to the ring kernels
+    (gemm_resident = 0) -- full, ragged and single-slice shapes, K / 64 not a multiple of the chunk, every epilogue the decoder
+    uses (bias, GELU, gate, fp32 residual; bf16-only output; bf16 residual stream)."""
+    pol = bare_policy("bf16")
+    g = torch.Generator().manual_seed(21)
+    shapes = [(8, 768, 3072), (9, 768, 768), (32, 2304, 768), (18, 3072, 768), (40, 768, 768), (200, 768, 768), (288, 768, 3072),
+              (500, 1536, 768), (33, 100, 192), (5, 36, 64), (64, 96, 320)]
+    combos = [(0, False, False, False), (0, True, False, True), (2, True, True, False), (2, False, True, True), (1, True, False, False),
+              (3, True, False, True)]
+    try:
+        for M, N, K in shapes:
+            A, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+            b, mu, r = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+            for mode in ("f32out", "bf16out", "streamT"):
+                pol.set_option("op_bf16_out", 1 if mode == "bf16out" else 0)
+                pol.set_option("op_stream_T", 1 if mode == "streamT" else 0)
+                for act, ub, um, ur in combos:
+                    if mode == "streamT" and (act != 0 or not ur):
+                        continue                      # the bf16-stream epilogue is a residual epilogue without activation
+                    outs = {}
+                    for name, res, tile in (("ring", 0, 0), ("auto", 1, 0), ("t32x32", 1, 10), ("t64x32", 1, 11), ("t64x64", 1, 12)):
+                        pol.set_option("gemm_resident", res)
+                        pol.set_option("gemm_tile", tile)
+                        out = torch.full((M, N), float("nan"), device="cuda")
+                        _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(A), ptr(W), ptr(b) if ub else None, ptr(mu) if um else None,
+                                                           ptr(r) if ur else None, M, N, K, act, ptr(out), pol._stream()))
+                        torch.cuda.synchronize()
+                        outs[name] = out
+                    assert not torch.isnan(outs["ring"]).any()
+                    for name in ("auto", "t32x32", "t64x32", "t64x64"):
+                        d = (outs[name] - outs["ring"]).abs().max().item()
+                        assert torch.equal(outs[name], outs["ring"]), (M, N, K, mode, act, ub, um, ur, name, d)
+    finally:
+        for k, v in (("gemm_resident", 1), ("gemm_tile", 0), ("op_bf16_out", 0), ("op_stream_T", 0)):
+            pol.set_option(k, v)
+
+
 def test_linear_transpose_detecting():
     """A = I with an asymmetric W: output must equal W^T exactly (catches swapped C-layout / operand order)."""
     pol = bare_policy("fp32")

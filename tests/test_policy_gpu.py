@@ -146,7 +146,7 @@ def test_bf16_argmax_agreement_o1_logits_live_oracle():
 
 
 
-@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 2}, {"gemm_wide": 1}, {"gemm_pp": 0}, {"graphs": 1},
+@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 2}, {"gemm_wide": 1}, {"gemm_pp": 0}, {"graphs": 1}, {"gemm_resident": 0},
                                   {"dual_stream": 0}, {"attn_split": 0}, {"gemm_epi": 0}, {"vit_prune_last": 0}])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_every_option_matches_reference_golden(opts, prec, golden_dir):
@@ -166,7 +166,7 @@ def test_every_option_matches_reference_golden(opts, prec, golden_dir):
         assert max_rel(out["prompt_tokens"].cpu(), tok) < (2e-4 if prec == "fp32" else 4e-2)
     finally:
         for k in opts:                                         # (options are per handle; restoring is belt and braces)
-            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 1, "gemm_wide": 0, "gemm_pp": 1, "graphs": 0, "dual_stream": 1,
+            pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 1, "gemm_wide": 0, "gemm_pp": 1, "graphs": 0, "dual_stream": 1, "gemm_resident": 1,
                                "attn_split": 1, "gemm_epi": 1, "vit_prune_last": 1}[k])
 
 
@@ -226,6 +226,25 @@ def test_dual_stream_and_pruning_are_exact():
     for o in outs[1:]:
         for k in ("prompt_tokens", "obs_tokens", "predicted", "raw_logits"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("name", ["e384_long", "ragged_4M"])
+def test_resident_gemm_kernel_is_exact_in_the_policy(name):
+    """gemm_resident_kernel takes the underfilled GEMM grids of a small-batch step (decoder, action head, T5 / ViT at batch <= 4,
+    incl. the fused-RMSNorm producers / consumers and the K/V-cache appends of incremental decoding); it accumulates K in the
+    ring tiles' order, so every output of the policy must be BIT-identical with and without it -- also with a grid limit that
+    sends the mid-size problems to it."""
+    cfg, wseed, prompts, obs, actions = build_case(name)
+    sd = syn.make_state_dict(cfg, wseed)
+    outs = []
+    for res, maxwg in ((0, 256), (1, 256), (1, 4096)):
+        pol = loaded_policy(cfg, sd, "bf16", gemm_resident=res, gemm_res_maxwg=maxwg)
+        for _ in range(2):
+            o = native_outputs(pol, prompts, obs, actions)
+        outs.append(o)
+    for o in outs[1:]:
+        for k in ("prompt_tokens", "obs_tokens", "predicted", "raw_logits"):
+            assert torch.equal(o[k], outs[0][k]), (k, (o[k].float() - outs[0][k].float()).abs().max().item())
 
 
 def test_t5_fused_rmsnorm_matches_unfused():

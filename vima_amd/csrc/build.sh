@@ -10,7 +10,7 @@ pids=()
 for f in gemm elementwise attention vima_api comm preprocess baseline_kernels; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kernels.h" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/vima_hip.h" -nt "$obj" ] \
-     || { [ "$f" = vima_api ] && [ "$HERE/baselines.inc" -nt "$obj" ]; }; then
+     || { [ "$f" = vima_api ] && [ "$HERE/baselines.inc" -nt "$obj" ]; } || { [ "$f" = gemm ] && [ "$HERE/gemm_small.inc" -nt "$obj" ]; }; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

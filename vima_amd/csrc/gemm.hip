@@ -1596,6 +1596,10 @@ __global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const Gemm
   }
 }
 
+#ifndef VIMA_GEMM_LAB
+#include "gemm_small.inc"   // gemm_resident_kernel: underfilled grids (batch 1 .. 32, one env step), whole K in flight
+#endif
+
 // Knob resolution: the handle's Tuning value when set (>= 0), otherwise the process default from the environment
 // (read once; never written afterwards, so it is safe to share between handles).
 inline int env_int(const char* name, int dflt) {
@@ -1620,6 +1624,9 @@ int g_env_wide = -1;
 VIMA_KNOB(gemm_wide, gemm_wide, "VIMA_GEMM_WIDE", g_env_wide, 0)
 int g_env_pp = -1;
 VIMA_KNOB(gemm_pp, gemm_pp, "VIMA_GEMM_PP", g_env_pp, 1)
+int g_env_resident = -1, g_env_res_maxwg = -1;
+VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
+VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1846,6 +1853,56 @@ int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
   }
 }
 
+#ifndef VIMA_GEMM_LAB
+// ------------------------------------------------------------------------------------------------ resident-K tiles
+template <int BM, int BN, int ACT>
+int launch_resident_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
+  using RT = RTile<BM, BN>;
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_resident_kernel<BM, BN, ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RT::SMEM); });
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL((gemm_resident_kernel<BM, BN, ACT>), grid, dim3(RT::THREADS), RT::SMEM, st, d);
+  return (int)hipGetLastError();
+}
+template <int BM, int BN>
+int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  d.mtiles = (d.M + BM - 1) / BM;
+  d.ntiles = (d.N + BN - 1) / BN;
+  const dim3 grid((unsigned)(d.mtiles * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  switch (a.act) {
+    case ACT_NONE: return launch_resident_inst<BM, BN, ACT_NONE>(d, grid, st);
+    case ACT_RELU: return launch_resident_inst<BM, BN, ACT_RELU>(d, grid, st);
+    case ACT_GELU: return launch_resident_inst<BM, BN, ACT_GELU>(d, grid, st);
+    case ACT_QUICKGELU: return launch_resident_inst<BM, BN, ACT_QUICKGELU>(d, grid, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+// bf16 problems with a vector-aligned epilogue and no fp8 operands. Tile: 32x32 for M <= 32 (one env step at batch <= 3), else
+// 64x32 while that grid fits the chip once (`gemm_res_maxwg`, default 256 = one workgroup per CU), else 64x64; < 0 = not taken.
+// `force`: gemm_tile 10 / 11 / 12 = 32x32 / 64x32 / 64x64 whatever the grid size.
+int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t st) {
+  if (a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || a.N % 4 != 0) return -1;
+  if (a.ssq_out && a.act != ACT_NONE) return -1;
+  const long long nb = a.batch > 0 ? a.batch : 1;
+  const long long maxwg = gemm_res_maxwg(a.tune);
+  const long long m64 = (a.M + 63) / 64;
+  int tile = 0;
+  if (force) tile = force;
+  else if (a.M <= 32) tile = ((long long)((a.N + 31) / 32) * nb <= 4 * maxwg) ? 10 : 0;
+  else if (m64 * ((a.N + 31) / 32) * nb <= maxwg) tile = 11;
+  else if (m64 * ((a.N + 63) / 64) * nb <= maxwg) tile = 12;
+  if (!tile) return -1;
+  if (a.kernel_id) *a.kernel_id = tile * 1000 + (a.act + 1) * 10;
+  if (tile == 10) return launch_resident_tile<32, 32>(d, a, st);
+  if (tile == 11) return launch_resident_tile<64, 32>(d, a, st);
+  return launch_resident_tile<64, 64>(d, a, st);
+}
+#endif
+
+
 // ------------------------------------------------------------------------------------------------ split-K
 // With M = 8 .. 512 rows (batch 1 .. 32 decoder / prompt GEMMs) a 128x128 grid has 6 .. 100 workgroups, each walking
 // its K dimension serially at the per-CU operand-path rate (~23 B/clk): 8 us at K = 768, 30 us at K = 3072, most CUs
@@ -2001,6 +2058,14 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     // and spread the problem over more CUs. Every tile shape accumulates K in the same order, so results do not depend
     // on the choice.
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
+    {   // the same class with (almost) the whole K extent in flight (gemm_small.inc); bit-identical to the ring tiles
+      const int gt = gemm_tile(a.tune);
+      const int force = (gt >= 10 && gt <= 12) ? gt : 0;
+      if (v && (force || (gt == 0 && gemm_small(a.tune) && gemm_resident(a.tune) && t128 < 128))) {
+        const int e = launch_resident(d, a, force, st);
+        if (e >= 0) return e;
+      }
+    }
     if (v && gemm_tile(a.tune) == 0 && gemm_small(a.tune) && t128 < 128) {
       if (a.kernel_id) *a.kernel_id = (a.M <= 32 ? 7000 : 6000) + (a.act + 1) * 10;
       if (a.M <= 32) return launch_tile<T, TileXS, true>(d, a, v, st);

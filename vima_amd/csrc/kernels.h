@@ -9,7 +9,7 @@ namespace vima {
 // process never see each other's settings, and a handle's captured hipGraphs are keyed on its own generation counter.
 struct Tuning {
   int gemm_variant = -1;   // VIMA_GEMM_VARIANT  1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin (TileS)
-  int gemm_tile = -1;      // VIMA_GEMM_TILE     0 auto, 1 128x128, 2 256x256 8 waves, 7 32x64, 8 64x64
+  int gemm_tile = -1;      // VIMA_GEMM_TILE     0 auto, 1 128x128, 2 256x256 8 waves, 7 32x64, 8 64x64, 10 / 11 / 12 resident-K 32x32 / 64x32 / 64x64
   int gemm_raster = -1;    // VIMA_GEMM_RASTER   tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
   int gemm_epi = -1;       // VIMA_GEMM_EPI      1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
   int gemm_persist = -1;   // VIMA_GEMM_PERSIST  1 = large bf16 GEMMs on the persistent kernel (default)
@@ -17,6 +17,8 @@ struct Tuning {
   int gemm_wide = -1;      // VIMA_GEMM_WIDE     1 = 256x384 persistent tile where N % 384 == 0 (bf16-out / bf16-residual epilogues)
   int gemm_pp = -1;        // VIMA_GEMM_PP       1 = ping-pong (8-phase) main loop on the persistent 256x256 kernel (default), 0 = the round-2 loop
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
+  int gemm_resident = -1;  // VIMA_GEMM_RESIDENT 1 = underfilled grids on gemm_resident_kernel (whole K in flight; default), 0 = the 4-deep ring tiles
+  int gemm_res_maxwg = -1; // VIMA_GEMM_RES_MAXWG largest grid (workgroups) that kernel takes at M > 32 (default 256 = one per CU)
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
   int attn4_min_lq = -1;   // Lq from which the 4-wave LDS-shared flash kernel is used (default 64)
@@ -67,7 +69,7 @@ struct GemmArgs {
   const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
   // out (profiling): which kernel the launcher chose = kind * 1000 + (act + 1) * 10 + epi ; kind 1 gemm_pp_kernel,
   // 2 gemm_persistent_kernel, 3 gemm_wide_kernel, 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile (epi 0),
-  // 8 two-pass split-K
+  // 8 two-pass split-K, 10 / 11 / 12 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 tile
   int* kernel_id = nullptr;
   // fp8 weights (precision "fp8w", bf16 activations): W is [N,K] OCP e4m3 BYTES (ldw / bsW in elements = bytes) and
   // wscale[n] the per-output-channel dequantisation scale; the kernel widens the fragments to bf16 in registers and

@@ -532,7 +532,8 @@ class VIMAPolicy(nn.Module):
 
     _GEMM_KINDS = {1: "vima::gemm_pp_kernel", 2: "vima::gemm_persistent_kernel", 3: "vima::gemm_wide_kernel",
                    4: "vima::gemm_kernel<Tile<256, 256>>", 5: "vima::gemm_kernel<Tile<128, 128>>", 6: "vima::gemm_kernel<Tile<64, 64>>",
-                   7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)", 9: "vima::gemm_pp_kernel"}
+                   7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)", 9: "vima::gemm_pp_kernel",
+                   10: "vima::gemm_resident_kernel<32, 32>", 11: "vima::gemm_resident_kernel<64, 32>", 12: "vima::gemm_resident_kernel<64, 64>"}
 
     def prof_read_gemm_kernels(self):
         """GEMM launches recorded since prof_enable(True), grouped by the kernel the launcher chose (call BEFORE prof_read /
