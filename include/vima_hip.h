@@ -243,6 +243,8 @@ int vima_t5_bucket(int relative_position);
  *                            "gemm_resident" [1] underfilled grids on gemm_resident_kernel ((almost) the whole K extent in flight, one
  *                                               barrier per chunk of K-slices; bit-identical to the ring tiles), 0: the 4-deep ring tiles
  *                            "gemm_res_maxwg" [256] largest grid (workgroups) gemm_resident_kernel takes for M > 32
+ *                            "gemm_res_nch" [0] chunk buffers of its LDS ring: 0 = default (4 / 5 / 4 for the 32x32 / 64x32 / 64x64 tile: 128 KiB),
+ *                                               up to 5 / 6 / 5 (160 KiB)
  *                            "gemm_splitk"  [0] deterministic two-pass split-K for underfilled grids with K >= 1536
  *                            "gemm_raster"  [0] tile order of the one-tile-per-workgroup kernels: 0 XCD x n-walk, 1 XCD x
  *                                               resident n-group, 2 row-major

@@ -32,11 +32,13 @@ def micro():
             out = torch.empty(M, N, device="cuda")
             ref = None
             line = f"M{M:5d} N{N:5d} K{K:5d} act{act}:"
-            for name, res, tile in (("ring", 0, 0), ("auto", 1, 0), ("32x32", 1, 10), ("64x32", 1, 11), ("64x64", 1, 12)):
-                if name == "32x32" and M > 64:
+            for name, res, tile, nch in (("ring", 0, 0, 0), ("auto", 1, 0, 0), ("32x32", 1, 10, 0), ("64x32", 1, 11, 0), ("64x64", 1, 12, 0),
+                                         ("32x32/160K", 1, 10, 8), ("64x64/160K", 1, 12, 8)):
+                if name.startswith("32x32") and M > 64:
                     continue
                 pol.set_option("gemm_resident", res)
                 pol.set_option("gemm_tile", tile)
+                pol.set_option("gemm_res_nch", nch)
                 for _ in range(3):
                     _lib.check(pol._lib.vima_op_linear(pol._handle, p(A), p(W), None, None, None, M, N, K, act, p(out), pol._stream()))
                 torch.cuda.synchronize()
@@ -54,6 +56,7 @@ def micro():
                 line += f"  {name} {us:6.2f} us{'' if same else ' DIFFERENT'}" + (f" [{kinds}]" if name == "auto" else "")
             print(line, flush=True)
     pol.set_option("gemm_tile", 0)
+    pol.set_option("gemm_res_nch", 0)
 
 
 def steps(n):

@@ -257,20 +257,22 @@ def test_resident_kernel_matches_ring_tiles_bitwise():
                     if mode == "streamT" and (act != 0 or not ur):
                         continue                      # the bf16-stream epilogue is a residual epilogue without activation
                     outs = {}
-                    for name, res, tile in (("ring", 0, 0), ("auto", 1, 0), ("t32x32", 1, 10), ("t64x32", 1, 11), ("t64x64", 1, 12)):
+                    for name, res, tile, nch in (("ring", 0, 0, 0), ("auto", 1, 0, 0), ("t32x32", 1, 10, 0), ("t64x32", 1, 11, 0), ("t64x64", 1, 12, 0),
+                                                 ("t32x32/2buf", 1, 10, 2), ("t64x64/3buf", 1, 12, 3)):
                         pol.set_option("gemm_resident", res)
                         pol.set_option("gemm_tile", tile)
+                        pol.set_option("gemm_res_nch", nch)
                         out = torch.full((M, N), float("nan"), device="cuda")
                         _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(A), ptr(W), ptr(b) if ub else None, ptr(mu) if um else None,
                                                            ptr(r) if ur else None, M, N, K, act, ptr(out), pol._stream()))
                         torch.cuda.synchronize()
                         outs[name] = out
                     assert not torch.isnan(outs["ring"]).any()
-                    for name in ("auto", "t32x32", "t64x32", "t64x64"):
+                    for name in ("auto", "t32x32", "t64x32", "t64x64", "t32x32/2buf", "t64x64/3buf"):
                         d = (outs[name] - outs["ring"]).abs().max().item()
                         assert torch.equal(outs[name], outs["ring"]), (M, N, K, mode, act, ub, um, ur, name, d)
     finally:
-        for k, v in (("gemm_resident", 1), ("gemm_tile", 0), ("op_bf16_out", 0), ("op_stream_T", 0)):
+        for k, v in (("gemm_resident", 1), ("gemm_tile", 0), ("gemm_res_nch", 0), ("op_bf16_out", 0), ("op_stream_T", 0)):
             pol.set_option(k, v)
 
 

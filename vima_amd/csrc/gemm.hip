@@ -242,6 +242,7 @@ struct GemmDev {
   int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
   int wide8;    // bf16-only output with 8-column alignment: 16-byte stores in the LDS epilogue
+  int res_nch;  // gemm_resident_kernel: chunk buffers in LDS
   long long* dbg;   // optional: 8 debug slots per workgroup (shader-clock stamps of the 4 phases, real time, placement)
 };
 
@@ -1627,6 +1628,8 @@ VIMA_KNOB(gemm_pp, gemm_pp, "VIMA_GEMM_PP", g_env_pp, 1)
 int g_env_resident = -1, g_env_res_maxwg = -1;
 VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
 VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
+int g_env_res_nch = -1;
+VIMA_KNOB(gemm_res_nch, gemm_res_nch, "VIMA_GEMM_RES_NCH", g_env_res_nch, 0)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1861,16 +1864,25 @@ int launch_resident_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
   static PerDeviceOnce attr;   // per instantiation, per device
   {
     const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_resident_kernel<BM, BN, ACT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, RT::SMEM); });
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RT::NCH * RT::CHUNK); });
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((gemm_resident_kernel<BM, BN, ACT>), grid, dim3(RT::THREADS), RT::SMEM, st, d);
+  hipLaunchKernelGGL((gemm_resident_kernel<BM, BN, ACT>), grid, dim3(RT::THREADS), (size_t)d.res_nch * RT::CHUNK, st, d);
   return (int)hipGetLastError();
 }
 template <int BM, int BN>
 int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  using RT = RTile<BM, BN>;
   d.mtiles = (d.M + BM - 1) / BM;
   d.ntiles = (d.N + BN - 1) / BN;
+  {   // chunk buffers: the option when set (2 .. what the LDS holds), else the default; never more than the problem has chunks
+    int nch = gemm_res_nch(a.tune);
+    if (nch <= 0) nch = RT::NCH_DEFAULT;
+    nch = nch < 2 ? 2 : (nch > RT::NCH ? RT::NCH : nch);
+    const int chunks = (a.K / 64 + RT::CS - 1) / RT::CS;
+    if (nch > chunks) nch = chunks < 1 ? 1 : chunks;
+    d.res_nch = nch;
+  }
   const dim3 grid((unsigned)(d.mtiles * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
   switch (a.act) {
     case ACT_NONE: return launch_resident_inst<BM, BN, ACT_NONE>(d, grid, st);

@@ -19,6 +19,7 @@ struct Tuning {
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
   int gemm_resident = -1;  // VIMA_GEMM_RESIDENT 1 = underfilled grids on gemm_resident_kernel (whole K in flight; default), 0 = the 4-deep ring tiles
   int gemm_res_maxwg = -1; // VIMA_GEMM_RES_MAXWG largest grid (workgroups) that kernel takes at M > 32 (default 256 = one per CU)
+  int gemm_res_nch = -1;   // VIMA_GEMM_RES_NCH  chunk buffers of that kernel's LDS ring (0 = default: 4 / 5 / 4 = up to 128 KiB; max 5 / 6 / 5 = 160 KiB)
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
   int attn4_min_lq = -1;   // Lq from which the 4-wave LDS-shared flash kernel is used (default 64)
