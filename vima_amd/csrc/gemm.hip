@@ -1883,6 +1883,7 @@ int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
     if (nch > chunks) nch = chunks < 1 ? 1 : chunks;
     d.res_nch = nch;
   }
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   const dim3 grid((unsigned)(d.mtiles * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
   switch (a.act) {
     case ACT_NONE: return launch_resident_inst<BM, BN, ACT_NONE>(d, grid, st);
