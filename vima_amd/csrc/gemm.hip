@@ -1630,6 +1630,8 @@ VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
 VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
 int g_env_res_nch = -1;
 VIMA_KNOB(gemm_res_nch, gemm_res_nch, "VIMA_GEMM_RES_NCH", g_env_res_nch, 0)
+int g_env_res_big = -1;
+VIMA_KNOB(gemm_res_big, gemm_res_big, "VIMA_GEMM_RES_BIG", g_env_res_big, 0)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1858,23 +1860,21 @@ int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
 
 #ifndef VIMA_GEMM_LAB
 // ------------------------------------------------------------------------------------------------ resident-K tiles
-template <int BM, int BN, int ACT>
+template <typename RT, int ACT>
 int launch_resident_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
-  using RT = RTile<BM, BN>;
   static PerDeviceOnce attr;   // per instantiation, per device
   {
-    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_resident_kernel<BM, BN, ACT>),
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_resident_kernel<RT, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RT::NCH * RT::CHUNK); });
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((gemm_resident_kernel<BM, BN, ACT>), grid, dim3(RT::THREADS), (size_t)d.res_nch * RT::CHUNK, st, d);
+  hipLaunchKernelGGL((gemm_resident_kernel<RT, ACT>), grid, dim3(RT::THREADS), (size_t)d.res_nch * RT::CHUNK, st, d);
   return (int)hipGetLastError();
 }
-template <int BM, int BN>
+template <typename RT>
 int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
-  using RT = RTile<BM, BN>;
-  d.mtiles = (d.M + BM - 1) / BM;
-  d.ntiles = (d.N + BN - 1) / BN;
+  d.mtiles = (d.M + RT::BM - 1) / RT::BM;
+  d.ntiles = (d.N + RT::BN - 1) / RT::BN;
   {   // chunk buffers: the option when set (2 .. what the LDS holds), else the default; never more than the problem has chunks
     int nch = gemm_res_nch(a.tune);
     if (nch <= 0) nch = RT::NCH_DEFAULT;
@@ -1886,32 +1886,38 @@ int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   const dim3 grid((unsigned)(d.mtiles * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
   switch (a.act) {
-    case ACT_NONE: return launch_resident_inst<BM, BN, ACT_NONE>(d, grid, st);
-    case ACT_RELU: return launch_resident_inst<BM, BN, ACT_RELU>(d, grid, st);
-    case ACT_GELU: return launch_resident_inst<BM, BN, ACT_GELU>(d, grid, st);
-    case ACT_QUICKGELU: return launch_resident_inst<BM, BN, ACT_QUICKGELU>(d, grid, st);
+    case ACT_NONE: return launch_resident_inst<RT, ACT_NONE>(d, grid, st);
+    case ACT_RELU: return launch_resident_inst<RT, ACT_RELU>(d, grid, st);
+    case ACT_GELU: return launch_resident_inst<RT, ACT_GELU>(d, grid, st);
+    case ACT_QUICKGELU: return launch_resident_inst<RT, ACT_QUICKGELU>(d, grid, st);
     default: return (int)hipErrorInvalidValue;
   }
 }
-// bf16 problems with a vector-aligned epilogue and no fp8 operands. Tile: 32x32 for M <= 32 (one env step at batch <= 3), else
-// 64x32 while that grid fits the chip once (`gemm_res_maxwg`, default 256 = one workgroup per CU), else 64x64; < 0 = not taken.
-// `force`: gemm_tile 10 / 11 / 12 = 32x32 / 64x32 / 64x64 whatever the grid size.
+// bf16 problems with a vector-aligned epilogue and no fp8 operands; < 0 = not taken. Tile (`force`: gemm_tile 10 .. 14 = 32x32 /
+// 64x32 / 64x64 / 128x64 / 128x128 whatever the grid): 32x32 for M <= 32 (one env step at batch <= 3), else 64x32 while that grid
+// fits the chip once (`gemm_res_maxwg`, default 256 = one workgroup per CU), else 64x64; with `gemm_res_big` the 128-row tiles take
+// what is left of the underfilled class (M >= 512: the decoder's GEMMs of a batch-256 env step).
 int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t st) {
   if (a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || a.N % 4 != 0) return -1;
   if (a.ssq_out && a.act != ACT_NONE) return -1;
   const long long nb = a.batch > 0 ? a.batch : 1;
   const long long maxwg = gemm_res_maxwg(a.tune);
-  const long long m64 = (a.M + 63) / 64;
+  const long long m64 = (a.M + 63) / 64, m128 = (a.M + 127) / 128;
   int tile = 0;
   if (force) tile = force;
   else if (a.M <= 32) tile = ((long long)((a.N + 31) / 32) * nb <= 4 * maxwg) ? 10 : 0;
   else if (m64 * ((a.N + 31) / 32) * nb <= maxwg) tile = 11;
   else if (m64 * ((a.N + 63) / 64) * nb <= maxwg) tile = 12;
+  else if (gemm_res_big(a.tune) && a.M >= 512) tile = (m128 * ((a.N + 63) / 64) * nb <= maxwg) ? 13 : 14;
   if (!tile) return -1;
   if (a.kernel_id) *a.kernel_id = tile * 1000 + (a.act + 1) * 10;
-  if (tile == 10) return launch_resident_tile<32, 32>(d, a, st);
-  if (tile == 11) return launch_resident_tile<64, 32>(d, a, st);
-  return launch_resident_tile<64, 64>(d, a, st);
+  switch (tile) {
+    case 10: return launch_resident_tile<RT32>(d, a, st);
+    case 11: return launch_resident_tile<RT64x32>(d, a, st);
+    case 12: return launch_resident_tile<RT64>(d, a, st);
+    case 13: return launch_resident_tile<RT128x64>(d, a, st);
+    default: return launch_resident_tile<RT128>(d, a, st);
+  }
 }
 #endif
 
@@ -2073,8 +2079,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
     {   // the same class with (almost) the whole K extent in flight (gemm_small.inc); bit-identical to the ring tiles
       const int gt = gemm_tile(a.tune);
-      const int force = (gt >= 10 && gt <= 12) ? gt : 0;
-      if (v && (force || (gt == 0 && gemm_small(a.tune) && gemm_resident(a.tune) && t128 < 128))) {
+      const int force = (gt >= 10 && gt <= 14) ? gt : 0;
+      if (v && (force || (gt == 0 && gemm_small(a.tune) && gemm_resident(a.tune) && (t128 < 128 || gemm_res_big(a.tune))))) {
         const int e = launch_resident(d, a, force, st);
         if (e >= 0) return e;
       }
