@@ -16,8 +16,7 @@ from vima_amd import _lib, synthetic as syn    # noqa: E402
 from vima_amd.policy import VIMAPolicy         # noqa: E402
 
 DEV = torch.device("cuda", 0)
-VARIANTS = [("ring", {"gemm_resident": 0, "gemm_res_big": 0}), ("resident", {"gemm_resident": 1, "gemm_res_big": 0}),
-            ("resident + 128-row tiles", {"gemm_resident": 1, "gemm_res_big": 1})]
+VARIANTS = [("ring", {"gemm_resident": 0}), ("resident", {"gemm_resident": 1})]
 
 
 def micro():
@@ -33,8 +32,8 @@ def micro():
             ref = None
             line = f"M{M:5d} N{N:5d} K{K:5d} act{act}:"
             for name, res, tile, nch in (("ring", 0, 0, 0), ("auto", 1, 0, 0), ("32x32", 1, 10, 0), ("64x32", 1, 11, 0), ("64x64", 1, 12, 0),
-                                         ("128x64", 1, 13, 0), ("128x128", 1, 14, 0), ("128x64/6buf", 1, 13, 6), ("128x128/5buf", 1, 14, 5)):
-                if (name.startswith("32x32") and M > 64) or (name.startswith("128") and M < 256) or (name.startswith("64") and M > 1024):
+                                         ("32x32/5buf", 1, 10, 5), ("64x64/5buf", 1, 12, 5)):
+                if name.startswith("32x32") and M > 600:
                     continue
                 pol.set_option("gemm_resident", res)
                 pol.set_option("gemm_tile", tile)

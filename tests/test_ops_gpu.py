@@ -236,8 +236,8 @@ def test_small_tiles_match_128_tile_bitwise():
 
 def test_resident_kernel_matches_ring_tiles_bitwise():
     """gemm_resident_kernel (underfilled grids: (almost) the whole K extent in flight, one barrier per chunk of K-slices) walks K
-    in the same order with the same matrix instruction as the ring tiles: every tile shape of it (gemm_tile 10 .. 14 =
-    32x32 / 64x32 / 64x64 / 128x64 / 128x128, forced whatever the grid) and the launcher's own choice must be BIT-identical to the ring kernels
+    in the same order with the same matrix instruction as the ring tiles: every tile shape of it (gemm_tile 10 / 11 / 12 =
+    32x32 / 64x32 / 64x64, forced whatever the grid) and the launcher's own choice must be BIT-identical to the ring kernels
     (gemm_resident = 0) -- full, ragged and single-slice shapes, K / 64 not a multiple of the chunk, every epilogue the decoder
     uses (bias, GELU, gate, fp32 residual; bf16-only output; bf16 residual stream)."""
     pol = bare_policy("bf16")
@@ -258,8 +258,7 @@ def test_resident_kernel_matches_ring_tiles_bitwise():
                         continue                      # the bf16-stream epilogue is a residual epilogue without activation
                     outs = {}
                     for name, res, tile, nch in (("ring", 0, 0, 0), ("auto", 1, 0, 0), ("t32x32", 1, 10, 0), ("t64x32", 1, 11, 0), ("t64x64", 1, 12, 0),
-                                                 ("t128x64", 1, 13, 0), ("t128x128", 1, 14, 0), ("t32x32/2buf", 1, 10, 2), ("t64x64/3buf", 1, 12, 3),
-                                                 ("t128x128/5buf", 1, 14, 5)):
+                                                 ("t32x32/2buf", 1, 10, 2), ("t64x64/3buf", 1, 12, 3), ("t64x64/5buf", 1, 12, 5)):
                         pol.set_option("gemm_resident", res)
                         pol.set_option("gemm_tile", tile)
                         pol.set_option("gemm_res_nch", nch)

@@ -237,8 +237,8 @@ def test_resident_gemm_kernel_is_exact_in_the_policy(name):
     cfg, wseed, prompts, obs, actions = build_case(name)
     sd = syn.make_state_dict(cfg, wseed)
     outs = []
-    for res, maxwg, big in ((0, 256, 0), (1, 256, 0), (1, 4096, 0), (1, 1, 1)):
-        pol = loaded_policy(cfg, sd, "bf16", gemm_resident=res, gemm_res_maxwg=maxwg, gemm_res_big=big)
+    for res, maxwg in ((0, 256), (1, 256), (1, 4096), (1, 8)):
+        pol = loaded_policy(cfg, sd, "bf16", gemm_resident=res, gemm_res_maxwg=maxwg)
         for _ in range(2):
             o = native_outputs(pol, prompts, obs, actions)
         outs.append(o)

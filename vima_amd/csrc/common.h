@@ -106,4 +106,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// GELU (erf form, nn.GELU()) for the bf16-operand kernels, whose output is rounded to bf16 (relative step 2^-8) anyway:
+// 1 + erf(v / sqrt 2) from the complementary error function in the Abramowitz-Stegun 7.1.26 form, erfc(x) = (a1 t + .. + a5 t^5) e^(-x^2),
+// t = 1 / (1 + p x), x = |v| / sqrt 2 (|error of erf| <= 1.5e-7), taken as erfc for v < 0 (no cancellation: the small values keep
+// their relative accuracy) and as 2 - erfc otherwise. One v_rcp, one v_exp and 11 plain VALU operations instead of libm's erff
+// (~50 instructions: measured 236 clocks per value, the larger part of a GELU GEMM's epilogue -- scripts/small_m_stamps.py).
+// The fp32-operand parity kernels keep erff.
+__device__ __forceinline__ float gelu_erf_bf16(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+  float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  q = __builtin_fmaf(q, t, 1.421413741f);
+  q = __builtin_fmaf(q, t, -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.254829592f);
+  const float e = (q * t) * __builtin_amdgcn_exp2f((x * x) * -1.44269504088896340736f);   // erfc(x), x >= 0
+  return (0.5f * v) * (v < 0.0f ? e : 2.0f - e);
+}
+// activation of a kernel with operand type T
+template <typename T> __device__ __forceinline__ float apply_act_t(float v, int act) {
+  if (sizeof(T) == 2 && act == ACT_GELU) return gelu_erf_bf16(v);
+  return apply_act(v, act);
+}
+
 }  // namespace vima

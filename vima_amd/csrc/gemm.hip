@@ -508,7 +508,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             const int nb = n0 + wn * WCOLS + nl;
             if (p.wscale && nb < p.N) { const float4 sc = load4(p.wscale + nb); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
             if (bias && nb < p.N) { const float4 b = load4(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-            if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+            if (act != ACT_NONE) { v.x = apply_act_t<T>(v.x, act); v.y = apply_act_t<T>(v.y, act); v.z = apply_act_t<T>(v.z, act); v.w = apply_act_t<T>(v.w, act); }
             *reinterpret_cast<float4*>(stage + l31 * LDE + nl) = v;
           }
         if constexpr (sizeof(T) == 2) {
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           if (bias) { const float4 b = load4(bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
           if (act != ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_t<T>(v[e], act);
           }
           if (mul) { const float4 g = load4(mul + (long long)m * p.ldmul + n); v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w; }
           if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (ne >= p.N) break;
             float x = v[e];
             if (bias) x += bias[ne];
-            x = apply_act(x, act);
+            x = apply_act_t<T>(x, act);
             if (mul) x *= Elem<T>::load(mul + (long long)m * p.ldmul + ne);
             if (res) x += res[(long long)m * p.ldres + ne];
             if (resT) x += Elem<T>::load(resT + (long long)m * p.ldresT + ne);
@@ -757,7 +757,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
           if (W8) { v[j].x *= scol[ni][j].x; v[j].y *= scol[ni][j].y; v[j].z *= scol[ni][j].z; v[j].w *= scol[ni][j].w; }
           if constexpr (HAS_BIAS) { v[j].x += bcol[ni][j].x; v[j].y += bcol[ni][j].y; v[j].z += bcol[ni][j].z; v[j].w += bcol[ni][j].w; }
-          if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
+          if (act != ACT_NONE) { v[j].x = apply_act_t<bf16_t>(v[j].x, act); v[j].y = apply_act_t<bf16_t>(v[j].y, act); v[j].z = apply_act_t<bf16_t>(v[j].z, act); v[j].w = apply_act_t<bf16_t>(v[j].w, act); }
         }
         if constexpr (EPI == 2) {        // x gate: 8 bf16 values
           const f32x4_t g = aux[sl & 1][it];
@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const Gemm
           for (int j = 0; j < 2; ++j) {
             v[j] = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + j) ^ f) << 2));
             if (p.bias) { v[j].x += bcol[j].x; v[j].y += bcol[j].y; v[j].z += bcol[j].z; v[j].w += bcol[j].w; }
-            if (act != ACT_NONE) { v[j].x = apply_act(v[j].x, act); v[j].y = apply_act(v[j].y, act); v[j].z = apply_act(v[j].z, act); v[j].w = apply_act(v[j].w, act); }
+            if (act != ACT_NONE) { v[j].x = apply_act_t<bf16_t>(v[j].x, act); v[j].y = apply_act_t<bf16_t>(v[j].y, act); v[j].z = apply_act_t<bf16_t>(v[j].z, act); v[j].w = apply_act_t<bf16_t>(v[j].w, act); }
           }
           if constexpr (EPI == 4) {
             const f32x4_t g = aux[sl & 1][it];
@@ -1630,8 +1630,6 @@ VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
 VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
 int g_env_res_nch = -1;
 VIMA_KNOB(gemm_res_nch, gemm_res_nch, "VIMA_GEMM_RES_NCH", g_env_res_nch, 0)
-int g_env_res_big = -1;
-VIMA_KNOB(gemm_res_big, gemm_res_big, "VIMA_GEMM_RES_BIG", g_env_res_big, 0)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1893,30 +1891,28 @@ int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
     default: return (int)hipErrorInvalidValue;
   }
 }
-// bf16 problems with a vector-aligned epilogue and no fp8 operands; < 0 = not taken. Tile (`force`: gemm_tile 10 .. 14 = 32x32 /
-// 64x32 / 64x64 / 128x64 / 128x128 whatever the grid): 32x32 for M <= 32 (one env step at batch <= 3), else 64x32 while that grid
-// fits the chip once (`gemm_res_maxwg`, default 256 = one workgroup per CU), else 64x64; with `gemm_res_big` the 128-row tiles take
-// what is left of the underfilled class (M >= 512: the decoder's GEMMs of a batch-256 env step).
+// bf16 problems with a vector-aligned epilogue and no fp8 operands; < 0 = not taken. Tile (`force`: gemm_tile 10 / 11 / 12 = 32x32 /
+// 64x32 / 64x64 whatever the grid): the smallest one whose grid still fits the chip once (`gemm_res_maxwg`, default 256 = one
+// workgroup per CU; M <= 32 always takes 32x32) -- a lone 32x32 accumulator per wave is a dependent MFMA chain, so what counts is
+// how many of them run side by side, not the operand bytes per FLOP (measured, profiles/r03_small_m.txt).
 int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t st) {
   if (a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || a.N % 4 != 0) return -1;
   if (a.ssq_out && a.act != ACT_NONE) return -1;
   const long long nb = a.batch > 0 ? a.batch : 1;
   const long long maxwg = gemm_res_maxwg(a.tune);
-  const long long m64 = (a.M + 63) / 64, m128 = (a.M + 127) / 128;
+  const long long m32 = (a.M + 31) / 32, m64 = (a.M + 63) / 64, n32 = (a.N + 31) / 32, n64 = (a.N + 63) / 64;
   int tile = 0;
   if (force) tile = force;
-  else if (a.M <= 32) tile = ((long long)((a.N + 31) / 32) * nb <= 4 * maxwg) ? 10 : 0;
-  else if (m64 * ((a.N + 31) / 32) * nb <= maxwg) tile = 11;
-  else if (m64 * ((a.N + 63) / 64) * nb <= maxwg) tile = 12;
-  else if (gemm_res_big(a.tune) && a.M >= 512) tile = (m128 * ((a.N + 63) / 64) * nb <= maxwg) ? 13 : 14;
+  else if (a.M <= 32) tile = (n32 * nb <= 4 * maxwg) ? 10 : 0;
+  else if (m32 * n32 * nb <= maxwg) tile = 10;
+  else if (m64 * n32 * nb <= maxwg) tile = 11;
+  else if (m64 * n64 * nb <= maxwg) tile = 12;
   if (!tile) return -1;
   if (a.kernel_id) *a.kernel_id = tile * 1000 + (a.act + 1) * 10;
   switch (tile) {
     case 10: return launch_resident_tile<RT32>(d, a, st);
     case 11: return launch_resident_tile<RT64x32>(d, a, st);
-    case 12: return launch_resident_tile<RT64>(d, a, st);
-    case 13: return launch_resident_tile<RT128x64>(d, a, st);
-    default: return launch_resident_tile<RT128>(d, a, st);
+    default: return launch_resident_tile<RT64>(d, a, st);
   }
 }
 #endif
@@ -1968,7 +1964,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
     v.x *= r; v.y *= r; v.z *= r; v.w *= r;
   }
   if (bias) { const float4 b = load4(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-  if (act != ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+  if (act != ACT_NONE) { v.x = apply_act_t<T>(v.x, act); v.y = apply_act_t<T>(v.y, act); v.z = apply_act_t<T>(v.z, act); v.w = apply_act_t<T>(v.w, act); }
   if (mul) { const float4 g = load4(mul + (long long)m * ldmul + n); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
   if (res) { const float4 r4 = load4(res + (long long)m * ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
   if (out32) store4(out32 + (long long)m * ld32 + n, v);
@@ -2079,8 +2075,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
     {   // the same class with (almost) the whole K extent in flight (gemm_small.inc); bit-identical to the ring tiles
       const int gt = gemm_tile(a.tune);
-      const int force = (gt >= 10 && gt <= 14) ? gt : 0;
-      if (v && (force || (gt == 0 && gemm_small(a.tune) && gemm_resident(a.tune) && (t128 < 128 || gemm_res_big(a.tune))))) {
+      const int force = (gt >= 10 && gt <= 12) ? gt : 0;
+      if (v && (force || (gt == 0 && gemm_small(a.tune) && gemm_resident(a.tune) && t128 < 128))) {
         const int e = launch_resident(d, a, force, st);
         if (e >= 0) return e;
       }

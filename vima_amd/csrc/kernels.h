@@ -9,7 +9,7 @@ namespace vima {
 // process never see each other's settings, and a handle's captured hipGraphs are keyed on its own generation counter.
 struct Tuning {
   int gemm_variant = -1;   // VIMA_GEMM_VARIANT  1 = inline-asm LDS-DMA pipeline (default), 0 = compiler-tracked builtin (TileS)
-  int gemm_tile = -1;      // VIMA_GEMM_TILE     0 auto, 1 128x128, 2 256x256 8 waves, 7 32x64, 8 64x64, 10 .. 14 resident-K 32x32 / 64x32 / 64x64 / 128x64 / 128x128
+  int gemm_tile = -1;      // VIMA_GEMM_TILE     0 auto, 1 128x128, 2 256x256 8 waves, 7 32x64, 8 64x64, 10 / 11 / 12 resident-K 32x32 / 64x32 / 64x64
   int gemm_raster = -1;    // VIMA_GEMM_RASTER   tile order: 0 XCD x n-walk, 1 XCD x resident n-group, 2 row-major
   int gemm_epi = -1;       // VIMA_GEMM_EPI      1 = LDS-transposed row-contiguous epilogue (default), 0 = direct
   int gemm_persist = -1;   // VIMA_GEMM_PERSIST  1 = large bf16 GEMMs on the persistent kernel (default)
@@ -19,7 +19,6 @@ struct Tuning {
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
   int gemm_resident = -1;  // VIMA_GEMM_RESIDENT 1 = underfilled grids on gemm_resident_kernel (whole K in flight; default), 0 = the 4-deep ring tiles
   int gemm_res_maxwg = -1; // VIMA_GEMM_RES_MAXWG largest grid (workgroups) that kernel takes at M > 32 (default 256 = one per CU)
-  int gemm_res_big = -1;   // VIMA_GEMM_RES_BIG  1 = that kernel's 128x64 / 128x128 tiles for the rest of the underfilled class (M >= 512); default 0
   int gemm_res_nch = -1;   // VIMA_GEMM_RES_NCH  chunk buffers of that kernel's LDS ring (0 = default: 4 / 5 / 4 = up to 128 KiB; max 5 / 6 / 5 = 160 KiB)
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
@@ -71,7 +70,7 @@ struct GemmArgs {
   const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
   // out (profiling): which kernel the launcher chose = kind * 1000 + (act + 1) * 10 + epi ; kind 1 gemm_pp_kernel,
   // 2 gemm_persistent_kernel, 3 gemm_wide_kernel, 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile (epi 0),
-  // 8 two-pass split-K, 10 .. 14 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 / 128x64 / 128x128 tile
+  // 8 two-pass split-K, 10 / 11 / 12 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 tile
   int* kernel_id = nullptr;
   // fp8 weights (precision "fp8w", bf16 activations): W is [N,K] OCP e4m3 BYTES (ldw / bsW in elements = bytes) and
   // wscale[n] the per-output-channel dequantisation scale; the kernel widens the fragments to bf16 in registers and
