@@ -44,7 +44,7 @@ def _usage(src):
 
 
 @pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src,patterns", [("gemm.hip", ["gemm_persistent_kernel", "gemm_pp_kernel", "gemm_wide_kernel", "gemm_kernelItNS0_4TileILi256ELi256"]),
+@pytest.mark.parametrize("src,patterns", [("gemm.hip", ["gemm_persistent_kernel", "gemm_pp_kernel", "gemm_wide_kernel", "gemm_kernelItNS0_4TileILi256ELi256", "gemm_resident_kernel"]),
                                           ("attention.hip", ["attn_mfma4_kernel", "attn_split_kernel"])])
 def test_hot_kernels_use_no_scratch(src, patterns):
     res = _usage(src)
