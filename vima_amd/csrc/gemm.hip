@@ -243,6 +243,7 @@ struct GemmDev {
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
   int wide8;    // bf16-only output with 8-column alignment: 16-byte stores in the LDS epilogue
   int res_nch;  // gemm_resident_kernel: chunk buffers in LDS
+  const int* grp_col;   // gemm_resident_kernel, grouped form (GemmArgs::grp_col): column starts of the groups, or nullptr
   long long* dbg;   // optional: 8 debug slots per workgroup (shader-clock stamps of the 4 phases, real time, placement)
 };
 
@@ -1896,7 +1897,7 @@ int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
 // workgroup per CU; M <= 32 always takes 32x32) -- a lone 32x32 accumulator per wave is a dependent MFMA chain, so what counts is
 // how many of them run side by side, not the operand bytes per FLOP (measured, profiles/r03_small_m.txt).
 int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t st) {
-  if (a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || a.N % 4 != 0) return -1;
+  if (a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || (a.N % 4 != 0 && !a.grp_col)) return -1;
   if (a.ssq_out && a.act != ACT_NONE) return -1;
   const long long nb = a.batch > 0 ? a.batch : 1;
   const long long maxwg = gemm_res_maxwg(a.tune);
@@ -1906,7 +1907,7 @@ int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t 
   else if (a.M <= 32) tile = (n32 * nb <= 4 * maxwg) ? 10 : 0;
   else if (m32 * n32 * nb <= maxwg) tile = 10;
   else if (m64 * n32 * nb <= maxwg) tile = 11;
-  else if (m64 * n64 * nb <= maxwg) tile = 12;
+  else if (m64 * n64 * nb <= maxwg || a.grp_col) tile = 12;
   if (!tile) return -1;
   if (a.kernel_id) *a.kernel_id = tile * 1000 + (a.act + 1) * 10;
   switch (tile) {
@@ -2003,7 +2004,11 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       return (int)hipGetLastError();
     }
   }
+  if (a.grp_col && (sizeof(T) != 2 || a.w8 || a.a8 || a.act != ACT_NONE || a.mul || a.res || a.resT || a.outT || a.out8 || a.ssq_out || a.rs_ssq ||
+                    a.rb > 0 || !a.out32 || a.K % 64 != 0 || !gemm_grouped_ok(a.tune)))
+    return (int)hipErrorInvalidValue;
   GemmDev d;
+  d.grp_col = a.grp_col;
   d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
@@ -2035,6 +2040,14 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     // RMS partials without the fp32 stream exist only in the 8-column layout (statistics of the stored bf16 values)
     if (a.ssq_out && !a.out32 && !d.wide8) return (int)hipErrorInvalidValue;
   }
+#ifndef VIMA_GEMM_LAB
+  if constexpr (sizeof(T) == 2) {
+    if (a.grp_col) {
+      const int e = launch_resident(d, a, 0, st);
+      return e >= 0 ? e : (int)hipErrorInvalidValue;
+    }
+  }
+#endif
   if constexpr (sizeof(T) == 2) {
     // TileL when the 256x256 grid still fills the chip (>= ~1 workgroup per CU) and padding waste is small
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
@@ -2110,5 +2123,12 @@ size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16) {
 }
 int gemm_splitk_enabled(const Tuning* t) { return gemm_splitk(t); }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
+int gemm_grouped_ok(const Tuning* t) {
+#ifdef VIMA_GEMM_LAB
+  return 0;
+#else
+  return gemm_tile(t) == 0 && gemm_small(t) && gemm_resident(t);
+#endif
+}
 
 }  // namespace vima

@@ -38,6 +38,10 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;
   int lda = 0, ldw = 0;
   int batch = 1;             // blockIdx.y; strides below in elements
+  // GROUPED form (batch = groups; bf16, gemm_resident_kernel only -- gemm_grouped_ok()): group z multiplies A + z * bsA with the rows
+  // [grp_col[z], grp_col[z + 1]) of ONE packed W [sum N_z, K] and writes bias + product to the same COLUMNS of out32 (fp32, any
+  // alignment: scalar stores); N = the largest group; no activation / mul / residual / outT. grp_col: DEVICE array [batch + 1].
+  const int* grp_col = nullptr;
   long long bsA = 0, bsW = 0, bsBias = 0, bsMul = 0, bsRes = 0, bs32 = 0, bsT = 0;
   const float* bias = nullptr;
   int act = ACT_NONE;
@@ -95,6 +99,7 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
 size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
 int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
+int gemm_grouped_ok(const Tuning* t);   // the grouped form (GemmArgs::grp_col) is available with this handle's knobs
 
 // ---------------------------------------------------------------- normalisation / elementwise
 // LayerNorm (rms=0: mean/var, affine) or T5 RMSNorm (rms=1: no mean, no bias). fp32 statistics.

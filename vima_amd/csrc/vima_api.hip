@@ -236,6 +236,8 @@ struct VimaHandle {
   };
   std::vector<DecLayer> dec;
   Lin head1; void* head2_W = nullptr; float* head2_b = nullptr; Lin head3[kNumHeadsOut];
+  // the 12 last layers (512 -> bins) packed for ONE grouped launch: W [700, 512] in logits order, bias [700], column starts [13]
+  void* head3_Wall = nullptr; float* head3_ball = nullptr; int* head3_col = nullptr;
   struct { float *w0, *b0; } act0[4];
   void* act1_W = nullptr; float* act1_b = nullptr; Lin act_post;
   // ---- baseline policies (policy_kind != VIMA; baselines.inc): the ViT above holds the rectangular variant (vit_S tokens per
@@ -523,6 +525,10 @@ int pack_all(VimaHandle* h) {
   {
     std::vector<float> w1((size_t)kNumHeadsOut * kHeadHidden * E), b1((size_t)kNumHeadsOut * kHeadHidden);
     std::vector<float> w2((size_t)kNumHeadsOut * kHeadHidden * kHeadHidden), b2((size_t)kNumHeadsOut * kHeadHidden);
+    std::vector<float> w3((size_t)kLogits * kHeadHidden), b3((size_t)kLogits);
+    int col3[kNumHeadsOut + 1];
+    col3[0] = 0;
+    for (int j = 0; j < kNumHeadsOut; ++j) col3[j + 1] = col3[j] + kHeadBins[j];
     int hidx = 0;
     bool ok = true;
     for (int k = 0; k < 4; ++k) {
@@ -543,12 +549,24 @@ int pack_all(VimaHandle* h) {
           ok = false;
         }
         h->head3[hidx] = P.linear(m + ".6", kHeadBins[hidx], kHeadHidden, true);
+        const HostParam* e3 = P.get(m + ".6.weight", {kHeadBins[hidx], kHeadHidden});
+        const HostParam* eb3 = P.get(m + ".6.bias", {kHeadBins[hidx]});
+        if (e3 && eb3) {
+          memcpy(&w3[(size_t)col3[hidx] * kHeadHidden], e3->data.data(), e3->data.size() * 4);
+          memcpy(&b3[(size_t)col3[hidx]], eb3->data.data(), eb3->data.size() * 4);
+        } else {
+          ok = false;
+        }
       }
     }
     if (ok) {
       h->head1.N = kNumHeadsOut * kHeadHidden; h->head1.K = E;
       P.pack_w(h->head1, w1); h->head1.b = P.up_f32(b1.data(), b1.size());
       h->head2_W = P.up_T(w2); h->head2_b = P.up_f32(b2.data(), b2.size());
+      if (h->bf16) {   // grouped launch of the last layers (bf16 operands; these matrices are below the fp8 size threshold)
+        h->head3_Wall = P.up_T(w3); h->head3_ball = P.up_f32(b3.data(), b3.size());
+        h->head3_col = reinterpret_cast<int*>(P.up_f32(reinterpret_cast<const float*>(col3), kNumHeadsOut + 1));
+      }
     }
   }
   // ---- action encoder (action_embd.py): sorted key order == kActKeys order
@@ -2067,6 +2085,13 @@ int vima_action_head(VimaHandle* h, const float* tokens, int Rn, float* out_logi
   a.M = Rn; a.N = kHeadHidden; a.K = kHeadHidden; a.batch = kNumHeadsOut; a.bias = h->head2_b; a.bsBias = kHeadHidden;
   a.act = ACT_RELU; a.outT = h2; a.ldT = HH; a.bsT = kHeadHidden;
   R.gemm(a);
+  if (h->head3_Wall && gemm_grouped_ok(&h->tune)) {   // the 12 last layers (512 -> 50 / 100 bins) as ONE grouped launch, bit-identical to the loop below
+    GemmArgs b;
+    b.A = h2; b.lda = HH; b.bsA = kHeadHidden; b.W = h->head3_Wall; b.ldw = kHeadHidden; b.M = Rn; b.N = 100; b.K = kHeadHidden;
+    b.batch = kNumHeadsOut; b.grp_col = h->head3_col; b.bias = h->head3_ball; b.out32 = out_logits; b.ld32 = kLogits;
+    R.gemm(b);
+    return R.err;
+  }
   int col = 0;
   for (int j = 0; j < kNumHeadsOut; ++j) {
     GemmArgs b;
