@@ -1904,7 +1904,7 @@ int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t 
   const long long m32 = (a.M + 31) / 32, m64 = (a.M + 63) / 64, n32 = (a.N + 31) / 32, n64 = (a.N + 63) / 64;
   int tile = 0;
   if (force) tile = force;
-  else if (a.M <= 32) tile = (n32 * nb <= 4 * maxwg) ? 10 : 0;
+  else if (a.M <= 32) tile = (n32 * nb <= 4 * maxwg || a.grp_col) ? 10 : 0;
   else if (m32 * n32 * nb <= maxwg) tile = 10;
   else if (m64 * n32 * nb <= maxwg) tile = 11;
   else if (m64 * n64 * nb <= maxwg || a.grp_col) tile = 12;
