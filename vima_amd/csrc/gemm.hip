@@ -244,6 +244,7 @@ struct GemmDev {
   int wide8;    // bf16-only output with 8-column alignment: 16-byte stores in the LDS epilogue
   int res_nch;  // gemm_resident_kernel: chunk buffers in LDS
   const int* grp_col;   // gemm_resident_kernel, grouped form (GemmArgs::grp_col): column starts of the groups, or nullptr
+  const void* A2; const void* W2; int lda2, ldw2;   // gemm_resident_kernel<RTile<.., DUAL>>: the gate product's operands
   long long* dbg;   // optional: 8 debug slots per workgroup (shader-clock stamps of the 4 phases, real time, placement)
 };
 
@@ -1871,7 +1872,25 @@ int launch_resident_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
   return (int)hipGetLastError();
 }
 template <typename RT>
+dim3 resident_geometry(GemmDev& d, const GemmArgs& a);
+template <typename RT, int ACT>
+int launch_resident_act(GemmDev d, const GemmArgs& a, hipStream_t st) {   // one activation only (the GEGLU pair: GELU)
+  const dim3 grid = resident_geometry<RT>(d, a);
+  return launch_resident_inst<RT, ACT>(d, grid, st);
+}
+template <typename RT>
 int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  const dim3 grid = resident_geometry<RT>(d, a);
+  switch (a.act) {
+    case ACT_NONE: return launch_resident_inst<RT, ACT_NONE>(d, grid, st);
+    case ACT_RELU: return launch_resident_inst<RT, ACT_RELU>(d, grid, st);
+    case ACT_GELU: return launch_resident_inst<RT, ACT_GELU>(d, grid, st);
+    case ACT_QUICKGELU: return launch_resident_inst<RT, ACT_QUICKGELU>(d, grid, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+template <typename RT>
+dim3 resident_geometry(GemmDev& d, const GemmArgs& a) {
   d.mtiles = (d.M + RT::BM - 1) / RT::BM;
   d.ntiles = (d.N + RT::BN - 1) / RT::BN;
   {   // chunk buffers: the option when set (2 .. what the LDS holds), else the default; never more than the problem has chunks
@@ -1883,14 +1902,7 @@ int launch_resident_tile(GemmDev d, const GemmArgs& a, hipStream_t st) {
     d.res_nch = nch;
   }
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
-  const dim3 grid((unsigned)(d.mtiles * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
-  switch (a.act) {
-    case ACT_NONE: return launch_resident_inst<RT, ACT_NONE>(d, grid, st);
-    case ACT_RELU: return launch_resident_inst<RT, ACT_RELU>(d, grid, st);
-    case ACT_GELU: return launch_resident_inst<RT, ACT_GELU>(d, grid, st);
-    case ACT_QUICKGELU: return launch_resident_inst<RT, ACT_QUICKGELU>(d, grid, st);
-    default: return (int)hipErrorInvalidValue;
-  }
+  return dim3((unsigned)(d.mtiles * d.ntiles), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
 }
 // bf16 problems with a vector-aligned epilogue and no fp8 operands; < 0 = not taken. Tile (`force`: gemm_tile 10 / 11 / 12 = 32x32 /
 // 64x32 / 64x64 whatever the grid): the smallest one whose grid still fits the chip once (`gemm_res_maxwg`, default 256 = one
@@ -1903,6 +1915,12 @@ int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t 
   const long long maxwg = gemm_res_maxwg(a.tune);
   const long long m32 = (a.M + 31) / 32, m64 = (a.M + 63) / 64, n32 = (a.N + 31) / 32, n64 = (a.N + 63) / 64;
   int tile = 0;
+  if (a.W2) {   // GEGLU pair: 32x32 for M <= 32, else 64x64 while its grid fits the chip once (the caller asks gemm_dual_ok() first)
+    tile = a.M <= 32 ? 15 : (m64 * n64 <= maxwg ? 16 : 0);
+    if (!tile || a.act != ACT_GELU) return -1;
+    if (a.kernel_id) *a.kernel_id = tile * 1000 + (a.act + 1) * 10;
+    return tile == 15 ? launch_resident_act<RT32D, ACT_GELU>(d, a, st) : launch_resident_act<RT64D, ACT_GELU>(d, a, st);
+  }
   if (force) tile = force;
   else if (a.M <= 32) tile = (n32 * nb <= 4 * maxwg || a.grp_col) ? 10 : 0;
   else if (m32 * n32 * nb <= maxwg) tile = 10;
@@ -2007,8 +2025,13 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.grp_col && (sizeof(T) != 2 || a.w8 || a.a8 || a.act != ACT_NONE || a.mul || a.res || a.resT || a.outT || a.out8 || a.ssq_out || a.rs_ssq ||
                     a.rb > 0 || !a.out32 || a.K % 64 != 0 || !gemm_grouped_ok(a.tune)))
     return (int)hipErrorInvalidValue;
+  if (a.W2 && (sizeof(T) != 2 || a.w8 || a.a8 || a.mul || a.res || a.resT || a.out32 || a.out8 || a.ssq_out || a.rs_ssq || a.rb > 0 || a.batch > 1 ||
+               a.grp_col || !a.outT || !a.A2 || a.K % 64 != 0 || a.N % 4 != 0 || !aligned_to(a.A2, 16) || !aligned_to(a.W2, 16) || (a.lda2 * es) % 16 ||
+               (a.ldw2 * es) % 16 || !gemm_dual_ok(a.tune, a.M, a.N)))
+    return (int)hipErrorInvalidValue;
   GemmDev d;
   d.grp_col = a.grp_col;
+  d.A2 = a.A2; d.W2 = a.W2; d.lda2 = a.lda2; d.ldw2 = a.ldw2;
   d.A = a.A; d.W = a.W; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldw = a.ldw;
   d.bsA = a.bsA; d.bsW = a.bsW; d.bsBias = a.bsBias; d.bsMul = a.bsMul; d.bsRes = a.bsRes; d.bs32 = a.bs32; d.bsT = a.bsT;
   d.bias = a.bias; d.act = a.act; d.mul = a.mul; d.ldmul = a.ldmul; d.res = a.res; d.ldres = a.ldres;
@@ -2042,7 +2065,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   }
 #ifndef VIMA_GEMM_LAB
   if constexpr (sizeof(T) == 2) {
-    if (a.grp_col) {
+    if (a.grp_col || a.W2) {
+      if (a.W2 && !v) return (int)hipErrorInvalidValue;
       const int e = launch_resident(d, a, 0, st);
       return e >= 0 ? e : (int)hipErrorInvalidValue;
     }
@@ -2123,6 +2147,11 @@ size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16) {
 }
 int gemm_splitk_enabled(const Tuning* t) { return gemm_splitk(t); }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
+int gemm_dual_ok(const Tuning* t, int M, int N) {
+  if (!gemm_grouped_ok(t) || M <= 0 || N <= 0 || N % 4 != 0) return 0;
+  if (M <= 32) return 1;
+  return (long long)((M + 63) / 64) * ((N + 63) / 64) <= gemm_res_maxwg(t) ? 1 : 0;
+}
 int gemm_grouped_ok(const Tuning* t) {
 #ifdef VIMA_GEMM_LAB
   return 0;

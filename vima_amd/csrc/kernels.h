@@ -42,6 +42,10 @@ struct GemmArgs {
   // [grp_col[z], grp_col[z + 1]) of ONE packed W [sum N_z, K] and writes bias + product to the same COLUMNS of out32 (fp32, any
   // alignment: scalar stores); N = the largest group; no activation / mul / residual / outT. grp_col: DEVICE array [batch + 1].
   const int* grp_col = nullptr;
+  // DUAL form (bf16, gemm_resident_kernel only -- ask gemm_dual_ok() first): out = act(A . W^T + bias) * bf16(A2 . W2^T), the value /
+  // gate pair of a GEGLU in ONE launch (W2 [N, K] row stride ldw2, A2 [M, K] row stride lda2; A2 may be A). Bit-identical to the two
+  // launches (gate stored in bf16, then read as `mul`). outT only; act = ACT_GELU; no mul / residual / batch.
+  const void* A2 = nullptr; const void* W2 = nullptr; int lda2 = 0, ldw2 = 0;
   long long bsA = 0, bsW = 0, bsBias = 0, bsMul = 0, bsRes = 0, bs32 = 0, bsT = 0;
   const float* bias = nullptr;
   int act = ACT_NONE;
@@ -99,6 +103,7 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
 size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
 int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
+int gemm_dual_ok(const Tuning* t, int M, int N);   // the DUAL form (GemmArgs::W2) is available for an [M, N] output with this handle's knobs
 int gemm_grouped_ok(const Tuning* t);   // the grouped form (GemmArgs::grp_col) is available with this handle's knobs
 
 // ---------------------------------------------------------------- normalisation / elementwise

@@ -678,7 +678,9 @@ struct Run {
       const double nb = a.batch > 0 ? a.batch : 1, es = (double)h->esz(), mn = (double)a.M * a.N;
       const double bytes = nb * ((double)a.M * a.K * es + (double)a.N * a.K * (a.w8 ? 1.0 : es) + (a.out32 ? mn * 4 : 0) + (a.outT ? mn * es : 0) +
                                  (a.res ? mn * 4 : 0) + (a.resT ? mn * es : 0) + (a.mul ? mn * es : 0) + (a.ssq_out ? (double)a.M * (a.N / 32) * 4 : 0));
-      prof_begin(((a.res && a.out32) || a.resT) ? 3 : 0, 2.0 * a.M * (double)a.N * a.K * nb, bytes);
+      const double two = a.W2 ? 2.0 : 1.0;   // GEGLU pair: two products in one launch
+      prof_begin(((a.res && a.out32) || a.resT) ? 3 : 0, two * 2.0 * a.M * (double)a.N * a.K * nb,
+                 bytes + (a.W2 ? nb * ((double)a.M * a.K * es + (double)a.N * a.K * es) : 0.0));
     }
     int kid = 0;
     a.kernel_id = &kid;
@@ -708,6 +710,19 @@ struct Run {
     a.bias = L.b; a.act = act; a.mul = mul; a.ldmul = ldmul; a.res = res; a.ldres = ldres;
     a.out32 = out32; a.ld32 = ld32; a.outT = outT; a.ldT = ldT;
     return gemm(a);
+  }
+  // u = GELU(A1 . L1^T + b1) * bf16(A2 . Lg^T): the value / gate pair of a GEGLU (components.py:31-33, 221-226). ONE dual-accumulator
+  // launch where the library has one for this shape (bf16 weights, underfilled grid: batch <= ~32), else the gate GEMM into `g` followed
+  // by the value GEMM with the gate as its epilogue multiplier -- bit-identical either way
+  int geglu(const void* A1, const Lin& L1, const void* A2, const Lin& Lg, int M, void* g, void* u) {
+    if (h->bf16 && !L1.ws && !Lg.ws && L1.N == Lg.N && L1.K == Lg.K && gemm_dual_ok(&h->tune, M, L1.N)) {
+      GemmArgs a;
+      a.A = A1; a.lda = L1.K; setW(a, L1); a.A2 = A2; a.lda2 = Lg.K; a.W2 = Lg.W; a.ldw2 = Lg.K;
+      a.M = M; a.N = L1.N; a.K = L1.K; a.bias = L1.b; a.act = ACT_GELU; a.outT = u; a.ldT = L1.N;
+      return gemm(a);
+    }
+    linear(A2, Lg.K, Lg, M, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, g, Lg.N);
+    return linear(A1, L1.K, L1, M, ACT_GELU, g, Lg.N, nullptr, 0, nullptr, 0, u, L1.N);
   }
   int ln(const float* in, long long ldin, const float* g, const float* b, float eps, int rms, int rows, int E, float* out32,
          void* outT) {
@@ -1864,8 +1879,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     R.attn(a, h->attn_impl);
     R.linear(ctx, E, D.ao, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, aT, E);            // + q residual
     R.ln(a32, E, D.xln2_g, D.xln2_b, 1e-5f, 0, rq, E, nullptr, qn);
-    R.linear(aT, E, D.gate, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, g, 4 * E);  // gate reads the UN-normed stream
-    R.linear(qn, E, D.l1, rq, ACT_GELU, g, 4 * E, nullptr, 0, nullptr, 0, u, 4 * E);
+    R.geglu(qn, D.l1, aT, D.gate, rq, g, u);                                              // gate reads the UN-normed stream
     R.linear(u, 4 * E, D.l2, rq, ACT_NONE, nullptr, 0, a32, E, x32, E, xT, E);
     // ---- Block.forward (components.py:23-37), post-LN
     AttnArgs s;
@@ -1894,8 +1908,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     R.attn(s, h->attn_impl);
     R.linear(ctx, E, D.c_proj, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, nullptr, 0);   // x + a
     R.ln(a32, E, D.ln1_g, D.ln1_b, 1e-5f, 0, rq, E, n32, nT);                           // n = ln_1(x + a)
-    R.linear(nT, E, D.mgate, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, g, 4 * E);
-    R.linear(nT, E, D.fc, rq, ACT_GELU, g, 4 * E, nullptr, 0, nullptr, 0, u, 4 * E);
+    R.geglu(nT, D.fc, nT, D.mgate, rq, g, u);
     R.linear(u, 4 * E, D.mproj, rq, ACT_NONE, nullptr, 0, n32, E, a32, E, nullptr, 0);  // n + m
     R.ln(a32, E, D.ln2_g, D.ln2_b, 1e-5f, 0, rq, E, x32, xT);                           // h = ln_2(n + m)
     if (R.err) return R.err;

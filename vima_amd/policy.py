@@ -534,7 +534,8 @@ class VIMAPolicy(nn.Module):
                    4: "vima::gemm_kernel<Tile<256, 256>>", 5: "vima::gemm_kernel<Tile<128, 128>>", 6: "vima::gemm_kernel<Tile<64, 64>>",
                    7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)", 9: "vima::gemm_pp_kernel",
                    10: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 4>>", 11: "vima::gemm_resident_kernel<RTile<64, 32, 2, 1, 2>>",
-                   12: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>>"}
+                   12: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>>", 15: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 2, true>> (GEGLU pair)",
+                   16: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 1, true>> (GEGLU pair)"}
 
     def prof_read_gemm_kernels(self):
         """GEMM launches recorded since prof_enable(True), grouped by the kernel the launcher chose (call BEFORE prof_read /
