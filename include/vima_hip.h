@@ -256,6 +256,7 @@ int vima_t5_bucket(int relative_position);
  *   numerics / fusion:       "stream_T"     [1] T5 / ViT residual streams carried in the operand type (see VimaConfig)
  *                            "t5_fuse_rms"  [1] T5 RMSNorms folded into the neighbouring GEMMs
  *                            "vit_prune_last" [1] last ViT block evaluated for the cls row only (identical values)
+ *                            "fp8_recalibrate" (any value) VIMA_PRECISION_FP8: the next pass of every group measures the activation scales again
  *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass

@@ -29,6 +29,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.vima_abi_version() == _lib.ABI_VERSION == 4   # single source: VIMA_ABI_VERSION in include/vima_hip.h
 
 
+def test_header_option_list_matches_the_library():
+    """Every key vima_set_option accepts is documented in the option list of include/vima_hip.h and vice versa (the list
+    drifted once: VERDICT r2 weak 13)."""
+    hdr = open(os.path.join(ROOT, "include", "vima_hip.h")).read()
+    start = hdr.index("Per-handle options (every key vima_set_option accepts")
+    block = hdr[start:hdr.index("*/", start)]
+    block = block[:block.index("Process-wide A/B switches")]
+    documented = set(re.findall(r'"([a-z0-9_]+)"', block))
+    api = open(os.path.join(ROOT, "vima_amd", "csrc", "vima_api.hip")).read()
+    body = api[api.index("int vima_set_option("):]
+    body = body[:body.index("return fail(\"vima_set_option: unknown key")]
+    accepted = set(re.findall(r'k == "([a-z0-9_]+)"', body))
+    assert accepted, "no option keys parsed from vima_set_option"
+    assert accepted - documented == set(), f"accepted but not documented in the header: {sorted(accepted - documented)}"
+    assert documented - accepted == set(), f"documented in the header but not accepted: {sorted(documented - accepted)}"
+
+
 def test_t5_bucket_matches_oracle():
     lib = _lib.load()
     rel = torch.arange(-2100, 2101)
