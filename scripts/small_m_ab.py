@@ -16,7 +16,10 @@ from vima_amd import _lib, synthetic as syn    # noqa: E402
 from vima_amd.policy import VIMAPolicy         # noqa: E402
 
 DEV = torch.device("cuda", 0)
-VARIANTS = [("ring", {"gemm_resident": 0}), ("resident", {"gemm_resident": 1})]
+VARIANTS = [("ring", {"gemm_resident": 0, "gemm_res_maxwg": 256, "gemm_res_nch": 0}), ("resident", {"gemm_resident": 1, "gemm_res_maxwg": 256, "gemm_res_nch": 0}),
+            # unmeasured at the end of round 3 (no GPU minutes left): 64-KiB rings = two workgroups per CU, so that the 432-workgroup grids of a
+            # batch-256 env step (M = 2304) are co-resident like the ring tiles' while keeping one barrier per chunk
+            ("resident, 2 buffers, grids <= 512", {"gemm_resident": 1, "gemm_res_maxwg": 512, "gemm_res_nch": 2})]
 
 
 def micro():
@@ -32,7 +35,7 @@ def micro():
             ref = None
             line = f"M{M:5d} N{N:5d} K{K:5d} act{act}:"
             for name, res, tile, nch in (("ring", 0, 0, 0), ("auto", 1, 0, 0), ("32x32", 1, 10, 0), ("64x32", 1, 11, 0), ("64x64", 1, 12, 0),
-                                         ("32x32/5buf", 1, 10, 5), ("64x64/5buf", 1, 12, 5)):
+                                         ("32x32/5buf", 1, 10, 5), ("64x64/5buf", 1, 12, 5), ("64x64/2buf", 1, 12, 2)):   # 2 buffers = 64 KiB: two workgroups per CU
                 if name.startswith("32x32") and M > 600:
                     continue
                 pol.set_option("gemm_resident", res)
