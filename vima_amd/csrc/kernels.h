@@ -78,7 +78,7 @@ struct GemmArgs {
   const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
   // out (profiling): which kernel the launcher chose = kind * 1000 + (act + 1) * 10 + epi ; kind 1 gemm_pp_kernel,
   // 2 gemm_persistent_kernel, 3 gemm_wide_kernel, 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile (epi 0),
-  // 8 two-pass split-K, 10 / 11 / 12 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 tile
+  // 8 two-pass split-K, 10 / 11 / 12 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 tile, 15 / 16 its DUAL (GEGLU pair) form on the 32x32 / 64x64 tile
   int* kernel_id = nullptr;
   // fp8 weights (precision "fp8w", bf16 activations): W is [N,K] OCP e4m3 BYTES (ldw / bsW in elements = bytes) and
   // wscale[n] the per-output-channel dequantisation scale; the kernel widens the fragments to bf16 in registers and
