@@ -553,8 +553,8 @@ def test_full_size_200m_headline_batch_against_reference(golden_dir):
     """BASELINE.json configs[2] exactly as bench.py runs it (VIMA-200M, B=256, Lp=512, Q=8, same seeds): rows
     0/5/100/255 of the FULL batch are compared with what the unmodified reference computed for those samples
     (tests/golden/bench_200M.npz) -- prompt tokens, obs tokens, predicted action tokens and the raw logits (1e-3 abs,
-    the north_star gate). Then size-independent properties: per-sample independence (a sub-batch reproduces its rows bit
-    for bit up to 1e-5), opt-in split-K, and the fp32-operand mode on the sub-batch."""
+    the north_star gate). Then size-independent properties: per-sample independence (a sub-batch -- and ONE sample alone, north_star's
+    batch 1 -- reproduces its rows bit for bit up to 1e-5), opt-in split-K, and the fp32-operand mode on the sub-batch."""
     gold = np.load(os.path.join(golden_dir, "bench_200M.npz"))
     cfg = syn.config("200M", xattn_n_positions=512)
     sd = syn.make_state_dict(cfg, 0)
@@ -584,6 +584,17 @@ def test_full_size_200m_headline_batch_against_reference(golden_dir):
     otok_s, omask_s = pol.forward_obs_token(syn.to_device(o_sub, DEV))
     logits_s = pol.action_logits(pol.forward(otok_s, omask_s, None, ptok_s, pmask_s)[-1])
     assert max_abs(logits_s, logits[sub]) < 1e-5, "samples of a batch must be independent"
+    # north_star's batch 1 at full size: sample sub[0] ALONE (M = 9 decoder rows: the 32x32 resident tiles, the grouped action head and
+    # the dual GEGLU launch) against the reference's logits for that sample and against its row of the batch-256 run
+    one = [sub[0]]
+    ptok_1, pmask_1 = pol.forward_prompt_assembly(syn.to_device(syn.cut_prompt(prompts, one), DEV))
+    otok_1, omask_1 = pol.forward_obs_token(syn.to_device(syn.cut_obs(obs, one), DEV))
+    logits_1 = pol.action_logits(pol.forward(otok_1, omask_1, None, ptok_1, pmask_1)[-1])
+    err1 = max_abs(logits_1, ref_logits[:1])
+    print(f"[parity] batch 1 (sample {sub[0]} alone) vs reference: max|logit err| {err1:.3e}; vs its row of the batch-256 run: "
+          f"{max_abs(logits_1, logits[one]):.3e}")
+    assert err1 < 1e-3, err1
+    assert max_abs(logits_1, logits[one]) < 1e-5, "a sample alone must reproduce its row of the full batch"
     # opt-in split-K for underfilled grids: the sub-batch then sums K in a different order than the full batch
     pol.set_option("gemm_splitk", 1)
     ptok_k, pmask_k = pol.forward_prompt_assembly(syn.to_device(p_sub, DEV))
