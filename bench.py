@@ -49,6 +49,9 @@ def flops_per_sample(E, N, Lp, n_prompt_obj, Q, T):
     return prompt + step, step
 
 
+_LIVE_PMC = None   # summary dict of live_pmc_traffic() once collected in this run
+
+
 def pmc_traffic(kernel=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/): the counters need their own profiler runs
     (FETCH_SIZE and WRITE_SIZE do not fit one pass), so bench.py reports the last committed measurement of this same command
@@ -56,10 +59,10 @@ def pmc_traffic(kernel=None):
     carry a per-kernel table); without it, or for older summaries, the average over all bf16 GEMM launches. None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
+    if _LIVE_PMC is None and not files:
         return None
     try:
-        d = json.load(open(files[-1]))
+        d = _LIVE_PMC if _LIVE_PMC is not None else json.load(open(files[-1]))
         if kernel is not None:
             pk = d.get("per_kernel", {})
             key = kernel.replace(" ", "")
@@ -70,6 +73,93 @@ def pmc_traffic(kernel=None):
         return round(float(d["gemm_bf16_bytes_per_launch"]), 1)
     except Exception:
         return None
+
+
+def gpu_numa_cpus(dev_index: int):
+    """(numa_node, sorted cpu list) of the host CPUs local to GPU `dev_index`, from the PCI address torch reports and sysfs
+    (/sys/bus/pci/devices/<dddd:bb:dd.f>/{numa_node,local_cpulist}); None when any piece is unavailable."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{addr}"
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = []
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        return (node, sorted(cpus)) if cpus else None
+    except Exception:   # noqa: BLE001 -- no PCI ids in this torch build, no sysfs entry, node -1 ...
+        return None
+
+
+def pin_to_gpu_numa(dev_index: int):
+    """N > 1 ranks each issue ~500 launches per step: keep a rank's host threads on the NUMA node of ITS GPU.
+    Returns what was done, for the JSON line; never fails the run."""
+    info = gpu_numa_cpus(dev_index)
+    if info is None or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False, "reason": "GPU NUMA node / local cpulist not available"}
+    node, cpus = info
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if node < 0 or len(allowed) < 2:
+        return {"pinned": False, "numa_node": node, "reason": "no NUMA locality reported or too few allowed CPUs on that node"}
+    try:
+        os.sched_setaffinity(0, allowed)
+    except OSError as e:
+        return {"pinned": False, "numa_node": node, "reason": str(e)}
+    return {"pinned": True, "numa_node": node, "cpus": len(allowed)}
+
+
+def live_pmc_traffic(argv_tail, timeout_s=150.0):
+    """HBM bytes per launch measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a
+    subprocess running this same workload for one step with dual_stream = 0, which also writes the GEMM launch log (kernel, M, N, K
+    in launch order) so that per-dispatch counter values can be attributed to GEMM SHAPES (scripts/pmc_summary.py). Returns
+    (summary dict, None) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import pmc_summary
+    except Exception as e:   # noqa: BLE001
+        return None, f"scripts/pmc_summary.py not importable: {e}"
+    tmp = tempfile.mkdtemp(prefix="vima_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    log = os.path.join(tmp, "launches.json")
+    t_end = time.perf_counter() + timeout_s
+    dbs = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = os.path.join(tmp, ctr.lower())
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--headline-only", "--live-pmc", "off", "--opt", "dual_stream=0",
+               "--launch-log", log] + argv_tail
+        left = t_end - time.perf_counter()
+        if left < 10:
+            return None, "time budget for the live PMC passes exhausted"
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {ctr} pass timed out"
+        db = None
+        for root_, _, files in os.walk(out):
+            for f in files:
+                if f.endswith("_results.db"):
+                    db = os.path.join(root_, f)
+        if r.returncode != 0 or db is None:
+            return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+        dbs[ctr] = db
+    try:
+        summ = pmc_summary.summarise(dbs["FETCH_SIZE"], dbs["WRITE_SIZE"], log if os.path.exists(log) else None)
+    except Exception as e:   # noqa: BLE001
+        return None, f"pmc summary failed: {type(e).__name__}: {e}"
+    summ["source"] = "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over this workload, 1 step, dual_stream=0, in this bench.py run"
+    return summ, None
 
 
 def usable_cores() -> int:
@@ -88,7 +178,7 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
     """The oracle (torch fp32 port of the reference CPU path) timed on the host cores on a BOUNDED sample of the same
     workload. Thread count is calibrated first (a 256-thread host with a small cgroup quota is slower at 256 threads)."""
     from oracle.vima_oracle import OraclePolicy
-    from vima_amd import synthetic as syn
+    from vima_testing import synthetic as syn
     ncores = usable_cores()
     cands = sorted({max(1, ncores >> s) for s in range(0, 6)} | {min(ncores, 8)}, reverse=True)
     a = torch.randn(1024, 768)
@@ -136,7 +226,73 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
             "usable_cores": ncores, "host_cpu_count": os.cpu_count(), "threads_tried": cands}
 
 
-def extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B):
+def side_config(syn, sd_cache, dev, rank, *, model, batch, prompt_len, qv, words, precision, T, steps):
+    """One other BASELINE.json configuration on its own handle, outside the timed region: COLD step time (best of 3 x `steps`), the
+    library profiler's per-class split of one step and the MFMA roofline of the algorithmic FLOPs -- the FLOPs the fp8-operand GEMM kernels
+    (`gemm_pp_kernel<.., true>`) executed are priced against the 5 PF dense fp8 peak, everything else against 2.5 PF bf16."""
+    from vima_amd.policy import VIMAPolicy
+    Q = 2 * qv
+    seg = words + Q
+    assert prompt_len % seg == 0
+    n_seg = prompt_len // seg
+    cfg = syn.config(model, xattn_n_positions=max(256, prompt_len))
+    key = (model, cfg.xattn_n_positions)
+    if key not in sd_cache:
+        sd_cache[key] = syn.make_state_dict(cfg, 0)
+    pol = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision=precision, device=dev)
+    pol.load_state_dict(sd_cache[key], strict=True)
+    prompts = syn.to_device(syn.make_prompt(batch, n_segments=n_seg, words_per_segment=words, q_per_view=qv, seed=1236 + rank), dev)
+    obs = syn.to_device(syn.make_obs(T, batch, qv, seed=1336 + rank), dev)
+    past = syn.to_device(syn.make_actions(T - 1, batch, seed=1436 + rank), dev) if T > 1 else None
+
+    def step():
+        ptok, pmask = pol.forward_prompt_assembly(prompts)
+        otok, omask = pol.forward_obs_token(obs)
+        atok = pol.forward_action_token(past) if past is not None else None
+        return pol.action_logits(pol.forward(otok, omask, atok, ptok, pmask)[-1])
+
+    for _ in range(3):          # fp8: the first pass calibrates the activation scales (fp8w kernels), the next ones run fp8 activations
+        out = step()
+    torch.cuda.synchronize(dev)
+    assert bool(torch.isfinite(out).all())
+    ms = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        ms = min(ms, (time.perf_counter() - t0) / steps * 1e3)
+    pol.set_option("dual_stream", 0)
+    step()
+    torch.cuda.synchronize(dev)
+    pol.prof_enable(True)
+    step()
+    torch.cuda.synchronize(dev)
+    gk = pol.prof_read_gemm_kernels()
+    prof = pol.prof_read_ex()
+    pol.prof_enable(False)
+    cold, _ = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, prompt_len, n_seg * Q, Q, T)
+    f8 = sum(v["flops"] for k, v in gk.items() if k.endswith(", true>"))
+    total = batch * cold
+    t_roof = (min(f8, total) / (FP8_PEAK_TFLOPS * 1e12) + max(total - f8, 0.0) / (BF16_PEAK_TFLOPS * 1e12)) * 1e3
+    gemm_ms = prof["gemm"]["ms"] + prof["gemm_residual"]["ms"]
+    gemm_fl = prof["gemm"]["flops"] + prof["gemm_residual"]["flops"]
+    dom = max(gk, key=lambda k: gk[k]["ms"]) if gk else None
+    del pol
+    torch.cuda.empty_cache()
+    return {"workload": f"VIMA-{model} COLD policy forward, batch {batch}, {prompt_len}-token prompt ({n_seg} x [{words} words + 1 image]), "
+                        f"{Q} object tokens/obs, T={T}, {precision}",
+            "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 2), "samples_per_s": round(batch * 1e3 / ms, 1),
+            "timing": f"best of 3 x {steps} steps", "bound": "mfma", "roofline_ms": round(t_roof, 4), "roofline_frac": round(t_roof / ms, 4),
+            "algorithmic_tflop_per_step": round(total / 1e12, 3), "fp8_gemm_flop_share": round(f8 / total, 3) if total else 0.0,
+            "whole_step_tflops": round(total / (ms * 1e-3) / 1e12, 1),
+            "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
+            "gemm_ms": round(gemm_ms, 3), "attention_ms": round(prof["attention"]["ms"], 3), "other_ms": round(prof["other"]["ms"], 3),
+            "dominant_kernel": dom, "dominant_kernel_ms": round(gk[dom]["ms"], 3) if dom else None,
+            "dominant_kernel_tflops": round(gk[dom]["flops"] / (gk[dom]["ms"] * 1e-3) / 1e12, 1) if dom and gk[dom]["ms"] > 0 else None}
+
+
+def extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B, sd=None):
     """WARM step, incremental env step and the batch-1 / batch-32 cold steps (reported as extras, outside the timed region)."""
     secondary = {}
     # ---- WARM step (prompt tokens reused: obs ViT + decoder + action head), timed the same way, reported as an extra
@@ -211,6 +367,21 @@ def extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B
             "bound": "hbm" if t_hbm > t_mfma else "mfma", "roofline_ms": round(max(t_hbm, t_mfma), 4),
             "roofline_frac": round(max(t_hbm, t_mfma) / ms2, 4), "timing": f"best of 3 x {n2} steps"}
 
+    # ---- the other BASELINE.json configurations, driver-visible in the same record: configs[1] (VIMA-20M, batch 32,
+    # 256-token prompt, 4 object tokens / obs), the single-GPU share of configs[4] (1024-token prompt, bf16 and fp8) and T = 8 (the history
+    # re-fed like the reference's eval loop does). Only from the default workload (rank 0 of a 1-GPU run): they need their own handles.
+    default_run = (args.model == "200M" and B == 256 and args.prompt_len == 512 and args.precision == "bf16" and not args.opt
+                   and os.environ.get("WORLD_SIZE", "1") == "1")
+    if default_run and not args.no_side_configs:
+        sd_cache = {("200M", cfg.xattn_n_positions): sd} if sd is not None else {}
+        for name, kw in (("cfg2_20M", dict(model="20M", batch=32, prompt_len=256, qv=2, words=4, precision="bf16", T=1, steps=20)),
+                         ("lp1024_bf16", dict(model="200M", batch=256, prompt_len=1024, qv=4, words=8, precision="bf16", T=1, steps=3)),
+                         ("lp1024_fp8", dict(model="200M", batch=256, prompt_len=1024, qv=4, words=8, precision="fp8", T=1, steps=3)),
+                         ("t8", dict(model="200M", batch=256, prompt_len=512, qv=4, words=8, precision="bf16", T=8, steps=3))):
+            try:
+                secondary[name] = side_config(syn, sd_cache, dev, rank, **kw)
+            except Exception as e:   # noqa: BLE001 -- a side configuration must never take the headline line down
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"}
     return warm_ms, inc_ms, secondary
 
 
@@ -231,6 +402,13 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--steps-history", type=int, default=1, help="T: observation steps in the history (T-1 past actions)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (vima_set_option), repeatable")
+    ap.add_argument("--live-pmc", default="auto", choices=["auto", "off"], help="auto: collect roofline.traffic NOW with two rocprofv3 --pmc passes "
+                    "over a subprocess of this workload (1 GPU, default workload only, rocprofv3 on the box); off / unavailable: the last committed "
+                    "profiles/r*_pmc_traffic.json. The JSON line says which (roofline.traffic_source)")
+    ap.add_argument("--launch-log", default=None, help="write the GEMM launch log of one step (kernel, M, N, K in launch order) to this JSON file "
+                    "(scripts/pmc_summary.py joins it with per-dispatch counter values)")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the other BASELINE.json configurations (VIMA-20M batch 32, Lp = 1024 in bf16 "
+                    "and fp8, T = 8) that the default run reports under config.secondary_cold")
     args = ap.parse_args()
 
     # ---- N ranks: `--gpus N` without a torchrun environment re-launches this script under torch.distributed.run with one
@@ -264,6 +442,8 @@ def main():
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    host_affinity = pin_to_gpu_numa(local_rank) if world > 1 else {"pinned": False, "reason": "single rank: not pinned"}
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -274,7 +454,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()                  # the LIVE RCCL world size is what gets reported as n_gpus
 
-    from vima_amd import synthetic as syn, parallel
+    from vima_amd import parallel
+    from vima_testing import synthetic as syn
     from vima_amd.policy import VIMAPolicy
     collective = None
     if world > 1 and shared_gpu:
@@ -316,13 +497,25 @@ def main():
     obs = syn.to_device(syn.make_obs(T, B, args.qv, seed=1336 + rank), dev)
     past = syn.to_device(syn.make_actions(T - 1, B, seed=1436 + rank), dev) if T > 1 else None
 
-    def step():
+    ag_events = []    # (start, end) events around the logits all-gather of every TIMED step (N > 1): a bad scaling curve must be
+                      # attributable to the collective or to the ranks' own step time from the JSON line alone
+
+    def step(timed=False):
         ptok, pmask = pol.forward_prompt_assembly(prompts)
         otok, omask = pol.forward_obs_token(obs)
         atok = pol.forward_action_token(past) if past is not None else None
         pred = pol.forward(otok, omask, atok, ptok, pmask)
         logits = pol.action_logits(pred[-1])
-        return parallel.all_gather_logits(logits, global_batch=B * world, comm=comm) if world > 1 else logits
+        if world == 1:
+            return logits
+        if not timed:
+            return parallel.all_gather_logits(logits, global_batch=B * world, comm=comm)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()        # torch's current stream = the stream LogitsComm enqueues vima_allgather_logits on
+        out_ = parallel.all_gather_logits(logits, global_batch=B * world, comm=comm)
+        e1.record()
+        ag_events.append((e0, e1))
+        return out_
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -335,20 +528,33 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step(timed=True)
+    torch.cuda.synchronize(dev)
+    dt_own = time.perf_counter() - t0          # this rank's own K steps, before the closing barrier
     sync()
     dt = time.perf_counter() - t0
+    ranks_info = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        ag_us = sum(a.elapsed_time(b) for a, b in ag_events) / max(len(ag_events), 1) * 1e3
+        mine = torch.tensor([dt, dt_own, ag_us], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        dt = float(allr[:, 0].max())               # the contract: MAX over ranks of the barrier-bracketed time
+        own_ms = (allr[:, 1] / args.steps * 1e3).tolist()
+        ags = allr[:, 2].tolist()
+        ranks_info = {"ms_per_step_own": [round(v, 3) for v in own_ms], "ms_per_step_own_min": round(min(own_ms), 3),
+                      "ms_per_step_own_max": round(max(own_ms), 3), "slowest_rank": int(max(range(world), key=lambda r: own_ms[r])),
+                      "allgather_us": [round(v, 1) for v in ags], "allgather_us_min": round(min(ags), 1), "allgather_us_max": round(max(ags), 1),
+                      "note": "ms_per_step_own: each rank's K steps up to its own device synchronize (no barrier); allgather_us: HIP events around the "
+                              "logits all-gather on its stream, mean over the timed steps (includes waiting for the slowest rank to arrive)"}
     assert out.shape == (B * world, 700) and bool(torch.isfinite(out).all())
     ms_per_step = dt / args.steps * 1e3
 
     warm_ms = inc_ms = float("nan")
     secondary = {}
     if not args.headline_only:
-        warm_ms, inc_ms, secondary = extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B)
+        warm_ms, inc_ms, secondary = extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B, sd=sd)
 
     # ---- per-class kernel time (HIP events on the launch stream), same workload, outside the timed region. The
     # two-stream software pipelining is switched off for this pass so that kernels do not overlap each other and the
@@ -361,8 +567,25 @@ def main():
     step()
     torch.cuda.synchronize(dev)
     gk = pol.prof_read_gemm_kernels()           # per KERNEL (the launcher's choice), before the class read resets the records
+    if args.launch_log and rank == 0:
+        json.dump([{k: e[k] for k in ("kernel", "M", "N", "K")} for e in pol.prof_read_gemm_launches()], open(args.launch_log, "w"))
     prof = pol.prof_read_ex()
     pol.prof_enable(False)
+
+    # ---- HBM traffic of the dominant kernel: measured NOW when possible (two rocprofv3 --pmc passes over a subprocess of this same
+    # workload), else the last committed summary -- the line says which
+    global _LIVE_PMC
+    traffic_source = "committed profiles/r*_pmc_traffic.json (not collected in this run)"
+    default_workload = (world == 1 and args.model == "200M" and B == 256 and args.prompt_len == 512 and args.qv == 4 and args.words == 8
+                        and T == 1 and args.precision == "bf16" and not args.opt)
+    if args.live_pmc == "auto" and rank == 0 and default_workload and not args.headline_only:
+        t_pmc = time.perf_counter()
+        summ, why = live_pmc_traffic([])
+        if summ is not None:
+            _LIVE_PMC = summ
+            traffic_source = f"{summ['source']} ({time.perf_counter() - t_pmc:.0f} s)"
+        else:
+            traffic_source = f"committed profiles/r*_pmc_traffic.json (live collection unavailable: {why})"
 
     cold, warm = flops_per_sample(cfg.embed_dim, cfg.xf_n_layers, args.prompt_len, n_seg * Q, Q, T)
     peak = FP32_PEAK_TFLOPS if args.precision == "fp32" else BF16_PEAK_TFLOPS   # fp8w: fp8 weights are widened to bf16 in registers, the matrix op is the bf16 MFMA
@@ -396,6 +619,9 @@ def main():
     roofline.update({
         "traffic": pmc_traffic(dom_name) if dom_name else pmc_traffic(),
         "traffic_all_gemm_launches": pmc_traffic(),
+        "traffic_source": traffic_source,
+        "traffic_per_shape": ([{k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items()} for r in _LIVE_PMC["per_shape"][:12]]
+                              if _LIVE_PMC and _LIVE_PMC.get("per_shape") else None),
         "gemm_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0,
                              "algorithmic_mb_per_launch": round(v["bytes"] / max(v["launches"], 1) / 1e6, 1)}
@@ -436,7 +662,13 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:          # timed on rank 0's host cores, outside the timed region, for every N
-        cpu_baseline = run_cpu_baseline(cfg, sd, n_seg, args.qv, args.cpu_batch, B, words=args.words)
+        if affinity0 is not None and host_affinity.get("pinned"):
+            os.sched_setaffinity(0, affinity0)          # the NUMA pin was for the GPU step; the CPU baseline gets the cores the process was given
+        cpu_baseline = run_cpu_baseline(cfg, sd, n_seg, args.qv, args.cpu_batch, B, budget_s=20.0, words=args.words)
+    affinities = [host_affinity]
+    if world > 1:
+        affinities = [None] * world
+        dist.all_gather_object(affinities, host_affinity)
 
     if rank == 0:
         line = {
@@ -453,6 +685,7 @@ def main():
                        "incremental_env_step_ms": round(inc_ms, 3) if inc_ms == inc_ms else None,
                        "warm_roofline": warm_roof, "incremental_roofline": inc_roof,
                        "secondary_cold": secondary,
+                       "ranks": ranks_info, "host_affinity": affinities,
                        **({"shared_gpu_test": "all ranks on GPU 0 over gloo: exercises the launcher path, NOT a multi-GPU measurement"} if shared_gpu else {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -89,7 +89,7 @@ def main():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle.eval_loop import FixedTokenizer, SyntheticEnv, placeholders            # synthetic stand-ins for VIMA-Bench / the Hub
-    from vima_amd import synthetic as syn
+    from vima_testing import synthetic as syn
     from vima_amd.policy import VIMAPolicy
     from vima_amd.preprocess import prepare_obs, prepare_prompt_images
     ap = argparse.ArgumentParser()

@@ -32,7 +32,17 @@ enum { VIMA_PRECISION_FP32 = 0, VIMA_PRECISION_BF16 = 1, VIMA_PRECISION_FP8W = 2
 /* FP8W: bf16 activations and matrix instruction, OCP e4m3 weights (+ one fp32 scale per output channel) for the large Linear layers.
  * FP8 : FP8W plus e4m3 ACTIVATIONS into the large GEMMs of the T5 stack, the ViT and the decoder's prompt K/V projection (one static
  *       scale per layer and site, calibrated by the handle's first pass through each, which runs the FP8W kernels) on
- *       v_mfma_scale_f32_32x32x64_f8f6f4 -- BASELINE.json configs[4]. Shapes the fp8 kernel does not cover keep bf16 activations. */
+ *       v_mfma_scale_f32_32x32x64_f8f6f4 -- BASELINE.json configs[4]. Shapes the fp8 kernel does not cover, and handles whose kernel-
+ *       selection options leave that kernel unreachable (gemm_persist = 0, gemm_tile = 1, gemm_raster != 0, gemm_epi = 0, operands beyond the
+ *       32-bit LDS-DMA offsets), keep bf16 activations; no documented option makes a forward fail.
+ *       CALIBRATION CONTRACT: the scales are STATIC and come from the first eligible pass of each group, so (i) that first call runs the
+ *       FP8W kernels and the SAME input gives (slightly) different outputs on call 1 and on call 2 -- warm a handle up once on
+ *       representative data before comparing or serving; (ii) scale = headroom x max |x| / 448 with option "fp8_headroom_pct" (default 125):
+ *       later activations up to 1.25x the calibrating maximum stay representable, larger ones SATURATE at +-448 x scale silently (call
+ *       "fp8_recalibrate" when the input distribution changes); (iii) a calibrating batch that holds an inf / NaN activation is refused
+ *       (the call fails, nothing is frozen); (iv) vima_decode_restart rebuilds the restarted samples' prompt K/V rows with bf16
+ *       activations (M = Lp rows is below the fp8 kernel's size), i.e. a restarted sample matches a fresh episode to the fp8 tolerance, not
+ *       bit for bit. */
 
 /* Which policy class of vima/policy/ the handle implements. VIMA is the hot path (vima_policy.py); the other three are the
  * reference's baseline policies, which consume whole 64x128 RGB frames instead of object crops:
@@ -66,9 +76,10 @@ int vima_create(const VimaConfig* cfg, int device, VimaHandle** out);
 void vima_destroy(VimaHandle* h);
 const char* vima_last_error(void);
 /* 2: + vima_crop_objects, vima_comm_*, vima_allgather_logits, vima_prof_read_ex, precision fp8w; 3: + VimaConfig.policy_kind and the
- * baseline-policy entry points; 4: + VIMA_PRECISION_FP8, vima_fp8_act_scales, vima_decode_restart, vima_prof_read_gemm_kernels.
+ * baseline-policy entry points; 4: + VIMA_PRECISION_FP8, vima_fp8_act_scales, vima_decode_restart, vima_prof_read_gemm_kernels;
+ * 5: + vima_prof_read_gemm_launches, option "fp8_headroom_pct".
  * The ONE place the number lives: the library returns it, the ctypes binding parses it from this header and refuses a mismatch. */
-#define VIMA_ABI_VERSION 4
+#define VIMA_ABI_VERSION 5
 int vima_abi_version(void);
 
 /* ---- weights: the reference checkpoint contract -------------------------------------------------------------- */
@@ -221,7 +232,7 @@ int vima_op_layernorm(VimaHandle* h, const float* x, const float* gamma, const f
 int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float* v, const uint8_t* kmask,
                       const float* relbias, int B, int H, int Lq, int Lk, int D, float scale, int mode, int impl,
                       float* out, vima_stream_t stream);
-/* precision FP8: the calibrated activation scales (dequantisation scale = max |x| / 448) of group 0 the T5 stack [12 layers][4 sites:
+/* precision FP8: the calibrated activation scales (dequantisation scale = headroom x max |x| / 448, see VIMA_PRECISION_FP8) of group 0 the T5 stack [12 layers][4 sites:
  * stream before qkv, attention context, stream before wi, ReLU hidden], 1 the ViT [4 blocks][4 sites: ln_1 output, attention output,
  * ln_2 output, QuickGELU hidden], 2 the decoder's prompt K/V projection [1]; returns their number (0 before that group's calibrating
  * pass, < 0 on error). Option "fp8_recalibrate" makes the next pass of every group measure them again. */
@@ -257,6 +268,7 @@ int vima_t5_bucket(int relative_position);
  *                            "t5_fuse_rms"  [1] T5 RMSNorms folded into the neighbouring GEMMs
  *                            "vit_prune_last" [1] last ViT block evaluated for the cls row only (identical values)
  *                            "fp8_recalibrate" (any value) VIMA_PRECISION_FP8: the next pass of every group measures the activation scales again
+ *                            "fp8_headroom_pct" [125] VIMA_PRECISION_FP8: scale = pct/100 x max |x| / 448 (>= 100); setting it re-calibrates
  *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass
@@ -285,6 +297,11 @@ int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], 
  * launches, algorithmic FLOPs and algorithmic HBM bytes. Returns the number of kernels (<= max_n) or a negative error; does
  * NOT reset the records (call it before vima_prof_read / vima_prof_read_ex). */
 int vima_prof_read_gemm_kernels(VimaHandle* h, int max_n, int32_t* ids, double* ms, int64_t* launches, double* flops, double* bytes);
+/* The same records ONE BY ONE in launch order (ABI version 5): ids[i] as above, mnk[3 i .. 3 i + 2] = M, N, K of launch i, us[i] (may be
+ * NULL) its HIP-event duration in microseconds. With "dual_stream" 0 the launch order is the dispatch order of a rocprofv3 trace of the
+ * same call sequence, which is how scripts/pmc_summary.py attributes per-dispatch counter values to GEMM SHAPES. Returns the number of
+ * recorded GEMM launches (it may exceed max_n: only the first max_n are written) or a negative error; does not reset the records. */
+int vima_prof_read_gemm_launches(VimaHandle* h, int max_n, int32_t* ids, int32_t* mnk, float* us);
 /* bytes currently held by the workspace arena */
 int64_t vima_workspace_bytes(VimaHandle* h);
 /* hipGraph replay (vima_set_option(h, "graphs", 1)): the per-env-step entry points (vima_obs_encode, vima_decode,

@@ -245,6 +245,6 @@ ORACLES = {"gpt": OracleGPTPolicy, "gato": OracleGatoPolicy, "flamingo": OracleF
 
 
 def build_baseline_oracle(cfg, state_dict):
-    """cfg: vima_amd.synthetic.BaselineConfig"""
+    """cfg: vima_testing.synthetic.BaselineConfig"""
     return ORACLES[cfg.kind](state_dict, embed_dim=cfg.embed_dim, n_layer=cfg.n_layer, n_head=cfg.n_head,
                              xattn_n_heads=cfg.xattn_n_heads or None)

@@ -1,9 +1,9 @@
 """TEST INFRASTRUCTURE: the parity cases shared by `oracle/make_golden.py` (runs the reference here)
 and `tests/` (runs the oracle / the HIP path anywhere). Inputs and weights are regenerated from seeds
-(`vima_amd/synthetic.py`); only reference OUTPUTS are stored under tests/golden/."""
+(`vima_testing/synthetic.py`); only reference OUTPUTS are stored under tests/golden/."""
 from __future__ import annotations
 
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 
 # name -> dict(model, xattn_n_positions, batch, layout builder, q_per_view, steps, seeds)
 CASES = {

@@ -269,7 +269,7 @@ def run_reference_loop(policy, env, device="cpu"):
 # the numpy oracle: they let `examples/reference_loop.run_episode` run in a container without a GPU. The GPU functions are
 # checked bit-exact against the same oracle in tests/test_preprocess_gpu.py.
 def cpu_prepare_obs(*, obs, rgb_dict=None, meta, device=None):
-    from vima_amd.synthetic import MapDict
+    from vima_amd.containers import MapDict
     from .preprocess_oracle import prepare_obs_oracle
     assert not (rgb_dict is not None and "rgb" in obs)
     rgb = rgb_dict or obs.pop("rgb")
@@ -281,7 +281,7 @@ def cpu_prepare_obs(*, obs, rgb_dict=None, meta, device=None):
 
 
 def cpu_prepare_prompt_images(prompt_assets, names, views=VIEWS, device=None):
-    from vima_amd.synthetic import MapDict
+    from vima_amd.containers import MapDict
     from .preprocess_oracle import crop_objects_view
     views = sorted(views)
     per = {v: [] for v in views}

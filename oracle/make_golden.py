@@ -19,7 +19,7 @@ from oracle.cases import (CASES, BASELINE_CASES, build_case, run_policy, case_st
                           build_baseline_case, baseline_state_dict, run_baseline)
 from oracle.baseline_oracle import build_baseline_oracle  # noqa: E402
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS  # noqa: E402
-from vima_amd import synthetic as syn            # noqa: E402
+from vima_testing import synthetic as syn            # noqa: E402
 
 
 def ref_dists_to_arrays(dists):

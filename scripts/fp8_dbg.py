@@ -1,6 +1,6 @@
 import torch, sys
 sys.path.insert(0, '.')
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 from tests.gpu_common import loaded_policy, max_abs
 from tests.test_fp8_gpu import _case
 cfg, sd, prompts, obs = _case()

@@ -8,7 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from vima_amd import synthetic as syn  # noqa: E402
+from vima_testing import synthetic as syn  # noqa: E402
 from vima_amd.policy import VIMAPolicy  # noqa: E402
 
 DEFAULTS = {"gemm_tile": 0, "stream_T": 1, "dual_stream": 1, "gemm_persist": 1, "t5_fuse_rms": 1, "vit_chunk": 16384, "gemm_splitk": 0,

@@ -12,7 +12,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from vima_amd import _lib, synthetic as syn    # noqa: E402
+from vima_amd import _lib    # noqa: E402
+from vima_testing import synthetic as syn
 from vima_amd.policy import VIMAPolicy         # noqa: E402
 
 DEV = torch.device("cuda", 0)

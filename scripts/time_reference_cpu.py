@@ -13,7 +13,7 @@ import torch  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 from oracle.cases import run_policy  # noqa: E402
 from oracle.vima_oracle import OraclePolicy  # noqa: E402
-from vima_amd import synthetic as syn  # noqa: E402
+from vima_testing import synthetic as syn  # noqa: E402
 
 
 def main():

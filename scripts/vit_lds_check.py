@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from oracle.cases import build_case  # noqa: E402
-from vima_amd import synthetic as syn  # noqa: E402
+from vima_testing import synthetic as syn  # noqa: E402
 from tests.gpu_common import loaded_policy  # noqa: E402
 
 tag, prune, chunk = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

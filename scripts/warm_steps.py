@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from vima_amd import synthetic as syn  # noqa: E402
+from vima_testing import synthetic as syn  # noqa: E402
 from vima_amd.policy import VIMAPolicy  # noqa: E402
 
 

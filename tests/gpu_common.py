@@ -3,7 +3,8 @@ import ctypes
 
 import torch
 
-from vima_amd import _lib, synthetic as syn
+from vima_amd import _lib
+from vima_testing import synthetic as syn
 from vima_amd.policy import VIMAPolicy
 
 

@@ -7,7 +7,8 @@ import re
 import pytest
 import torch
 
-from vima_amd import _lib, synthetic as syn
+from vima_amd import _lib
+from vima_testing import synthetic as syn
 from oracle.vima_oracle import t5_relative_position_bucket
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/vima_hip.h but not exported by libvima_hip.so"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert lib.vima_abi_version() == _lib.ABI_VERSION == 4   # single source: VIMA_ABI_VERSION in include/vima_hip.h
+    assert lib.vima_abi_version() == _lib.ABI_VERSION == 5   # single source: VIMA_ABI_VERSION in include/vima_hip.h
 
 
 def test_header_option_list_matches_the_library():

@@ -10,7 +10,7 @@ import torch
 from oracle import ref_shim
 from oracle.baseline_oracle import build_baseline_oracle
 from oracle.cases import BASELINE_CASES, build_baseline_case, baseline_state_dict, run_baseline
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 
 ATOL = 5e-5
 

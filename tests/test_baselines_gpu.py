@@ -12,7 +12,8 @@ import torch
 
 from oracle.baseline_oracle import build_baseline_oracle
 from oracle.cases import BASELINE_CASES, build_baseline_case, baseline_state_dict, run_baseline
-from vima_amd import _lib, synthetic as syn
+from vima_amd import _lib
+from vima_testing import synthetic as syn
 from vima_amd.baselines import build_baseline
 from tests.gpu_common import max_abs, max_rel
 

@@ -14,7 +14,7 @@ import torch
 
 from oracle.cases import build_case, case_state_dict
 from oracle.vima_oracle import OraclePolicy
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 from tests.gpu_common import loaded_policy, max_abs
 
 pytestmark = pytest.mark.gpu

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 from oracle import eval_loop, ref_shim                      # noqa: E402
 from oracle.vima_oracle import OraclePolicy                 # noqa: E402
-from vima_amd import synthetic as syn                       # noqa: E402
+from vima_testing import synthetic as syn                       # noqa: E402
 import reference_loop                                       # noqa: E402  (examples/)
 
 MODEL, STEPS, N_OBJ, ENV_SEED, WSEED = "20M", 6, 4, 3, 7

@@ -10,7 +10,7 @@ import torch
 
 from oracle.fp8_quant import make_fp8_act_oracle
 from oracle.vima_oracle import OraclePolicy
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 from tests.gpu_common import loaded_policy, max_abs
 
 pytestmark = pytest.mark.gpu
@@ -135,3 +135,49 @@ def test_fp8_small_batches_fall_back_to_fp8w_kernels():
     a = loaded_policy(cfg, sd, "fp8").forward_prompt_assembly(prompts)[0]
     b = loaded_policy(cfg, sd, "fp8w").forward_prompt_assembly(prompts)[0]
     assert torch.equal(a, b)
+
+
+def test_fp8_keeps_bf16_activations_when_the_options_leave_the_fp8_kernel_unreachable():
+    """the fp8-activation GEMM exists on the ping-pong persistent kernel only. With a documented option that takes the large
+    GEMMs elsewhere (gemm_persist = 0, gemm_tile = 1, gemm_raster = 1) the forward must keep bf16 activations (fp8w kernels), not fail."""
+    cfg, sd, prompts, obs = _case()
+    p = syn.to_device(prompts, DEV)
+    ref = None
+    for key, val in (("gemm_persist", 0), ("gemm_tile", 1), ("gemm_raster", 1)):
+        pol = loaded_policy(cfg, sd, "fp8", dual_stream=0)
+        pol.set_option(key, val)
+        pol.forward_prompt_assembly(p)                    # would calibrate if the stage were eligible
+        assert pol.fp8_act_scales() is None, f"{key}={val}: the T5 stage must not be fp8-eligible"
+        pol.prof_enable(True)
+        ptok, pmask = pol.forward_prompt_assembly(p)      # used to fail with hipErrorInvalidValue inside launch_gemm
+        torch.cuda.synchronize()
+        kernels = pol.prof_read_gemm_kernels()
+        pol.prof_enable(False)
+        assert not any(k.endswith(", true>") for k in kernels), kernels.keys()
+        assert bool(torch.isfinite(ptok).all())
+        ref = ptok if ref is None else ref
+        assert max_abs(ptok, ref) < 1e-5                   # every tile shape accumulates K in the same order (fp8w path)
+
+
+def test_fp8_calibration_has_headroom_and_refuses_non_finite_maxima():
+    """scale = headroom x max |x| / 448 (option fp8_headroom_pct, default 125); a calibrating batch with an inf activation
+    is refused and leaves the handle uncalibrated."""
+    cfg, sd, prompts, obs = _case()
+    p = syn.to_device(prompts, DEV)
+    pol = loaded_policy(cfg, sd, "fp8", dual_stream=0)
+    pol.set_option("fp8_headroom_pct", 100)
+    pol.forward_prompt_assembly(p)
+    s100 = pol.fp8_act_scales().clone()
+    pol.set_option("fp8_headroom_pct", 125)              # re-calibrates
+    assert pol.fp8_act_scales() is None
+    pol.forward_prompt_assembly(p)
+    s125 = pol.fp8_act_scales()
+    assert torch.allclose(s125, s100 * 1.25, rtol=1e-6)
+    # poison: an infinite word embedding reaches the stream that enters the T5 stack
+    sd_bad = {k: v.clone() for k, v in sd.items()}
+    key = next(k for k in sd_bad if k.endswith("prompt_embedding._embed_layer.weight"))
+    sd_bad[key][:] = float("inf")
+    bad = loaded_policy(cfg, sd_bad, "fp8", dual_stream=0)
+    with pytest.raises(Exception, match="non-finite"):
+        bad.forward_prompt_assembly(p)
+    assert bad.fp8_act_scales() is None

@@ -14,7 +14,7 @@ import torch
 from oracle.cases import CASES, build_case, run_policy, case_state_dict
 from oracle.fp8_quant import fake_quant_state_dict
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 from tests.gpu_common import bare_policy, loaded_policy, max_abs, max_rel, ptr
 from tests.test_policy_gpu import native_outputs, _flip_report
 

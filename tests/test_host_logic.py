@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle.vima_oracle import OraclePolicy
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 from vima_amd.dists import MultiCategorical
 from vima_amd.policy import VIMAPolicy, build_prompt_index
 

@@ -8,7 +8,7 @@ import torch
 
 from oracle.cases import CASES, build_case, run_policy, case_state_dict, gold_view
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS, t5_relative_position_bucket
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 
 # fp32 summation-order noise between the reference's fused modules and the functional restatement
 ATOL = 5e-5

@@ -6,7 +6,7 @@ import torch
 from oracle import ref_shim
 from oracle.cases import build_case, run_policy
 from oracle.vima_oracle import OraclePolicy
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 
 pytestmark = pytest.mark.skipif(not ref_shim.reference_available(), reason="reference tree not present")
 

@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vima_amd import parallel, synthetic as syn
+from vima_amd import parallel
+from vima_testing import synthetic as syn
 
 
 def test_shard_bounds_cover_exactly():

@@ -12,7 +12,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vima_amd import parallel, synthetic as syn
+from vima_amd import parallel
+from vima_testing import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -120,3 +121,26 @@ def test_bench_launcher_path_with_two_ranks_on_the_one_gpu():
     assert "gloo" in d["config"]["collective"] and "shared_gpu_test" in d["config"]
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["cores"] >= 1      # carried into N > 1 lines
     assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def test_bench_launcher_path_with_eight_ranks_on_the_one_gpu():
+    """the first 8-GPU run must not also be the first run of the N = 8 host paths. Eight ranks share GPU 0 over gloo
+    (tiny model): rank agreement on the collective, per-rank step times, all-gather timing, MAX over ranks, NUMA pinning and the single
+    JSON line have all executed at world size 8; the line carries what a bad scaling curve would need to be diagnosed."""
+    import json
+    env = dict(os.environ, VIMA_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--model", "2M",
+                        "--batch", "2", "--prompt-len", "64", "--qv", "2", "--words", "4", "--headline-only", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8"
+    rk = d["config"]["ranks"]
+    assert len(rk["ms_per_step_own"]) == 8 and len(rk["allgather_us"]) == 8
+    assert 0 < rk["ms_per_step_own_min"] <= rk["ms_per_step_own_max"] <= d["ms_per_step"] * 1.001 + 1e-3
+    assert 0 <= rk["slowest_rank"] < 8 and all(v >= 0 for v in rk["allgather_us"])
+    assert len(d["config"]["host_affinity"]) == 8 and all("pinned" in a for a in d["config"]["host_affinity"])
+    assert d["value"] > 0

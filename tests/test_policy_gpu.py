@@ -12,7 +12,7 @@ import torch
 
 from oracle.cases import CASES, SMALL_CASES, BENCH_CASES, build_case, run_policy, case_state_dict, gold_view
 from oracle.vima_oracle import OraclePolicy, ACTION_KEYS
-from vima_amd import synthetic as syn
+from vima_testing import synthetic as syn
 from tests.gpu_common import loaded_policy, max_abs, max_rel
 
 pytestmark = pytest.mark.gpu

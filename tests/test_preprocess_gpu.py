@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from oracle.preprocess_oracle import crop_objects_view, prepare_obs_oracle, synthetic_frames
-from vima_amd import preprocess, synthetic as syn
+from vima_amd import preprocess
+from vima_testing import synthetic as syn
 from tests.gpu_common import loaded_policy
 
 pytestmark = pytest.mark.gpu

@@ -14,7 +14,7 @@ import os
 __all__ = ["VIMAPolicy", "VIMAGPTPolicy", "VIMAGatoPolicy", "VIMAFlamingoPolicy", "create_policy_from_ckpt"]
 
 
-def __getattr__(name):   # lazy: `import vima_amd.synthetic` must not need the built library
+def __getattr__(name):   # lazy: importing the package must not need the built library
     if name == "VIMAPolicy":
         from .policy import VIMAPolicy
         return VIMAPolicy

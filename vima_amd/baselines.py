@@ -192,6 +192,6 @@ BASELINES = {"gpt": VIMAGPTPolicy, "gato": VIMAGatoPolicy, "flamingo": VIMAFlami
 
 
 def build_baseline(cfg, precision="bf16", device=None):
-    """cfg: vima_amd.synthetic.BaselineConfig"""
+    """cfg: vima_testing.synthetic.BaselineConfig"""
     kw = cfg.ctor_kwargs()
     return BASELINES[cfg.kind](**kw, precision=precision, device=device)

@@ -98,6 +98,13 @@ __device__ __forceinline__ void glds16_asm_s(const void* sbase, unsigned voff, u
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
+// the same with the non-temporal cache policy: an operand every line of which is consumed once per XCD (the A stream of a short-K GEMM)
+// should not displace the re-used W panels from the XCD's L2
+__device__ __forceinline__ void glds16_asm_s_nt(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
 
 // wait for this wave's outstanding LDS-DMA + LDS reads, then workgroup barrier (compiler memory barrier too)
 // The vmcnt wait is inline asm (the DMA is invisible to hipcc); the lgkmcnt wait uses the BUILTIN so that hipcc's own
@@ -713,7 +720,11 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 3 ? 4 : 2);
+#ifdef VIMA_LAB_NORES   // timing-only ablation (scripts/micro/gemm_lab): the per-row operand is never loaded
+      asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(dst[it][0]), "=v"(dst[it][1]), "=v"(dst[it][2]), "=v"(dst[it][3]) : "v"(q));
+#else
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
+#endif
     }
   };
   if (AUX) issue_aux(0, aux[0]);
@@ -738,6 +749,9 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
         if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
         constexpr int kYoungLoads = NIT;
         f32x4_t(&a)[NIT] = aux[sl & 1];
+#ifdef VIMA_LAB_NORES
+        if (false) {} else if (true) {} else
+#endif
         if (sl == 0 || sl + 1 == NSLAB) {
           if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(kYoungLoads));
           else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(kYoungLoads));
@@ -784,7 +798,15 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
         if constexpr (WIDE8) {
           uint4 o;
           o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
+#ifdef VIMA_LAB_NOSTORE   // timing-only ablation: the output tile is never written
+          asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#elif defined(VIMA_LAB_NT_ST)   // experiment: non-temporal output stores (the output is never re-read by this kernel)
+          { typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            const T* q_ = outT + m * p.ldT + n; const u32x4_t ov = {o.x, o.y, o.z, o.w};
+            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(q_), "v"(ov) : "memory"); }
+#else
           if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+#endif
           if ((EPI == 1 || EPI == 4) && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
             const float q = p.out8_inv;
             auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); };
@@ -1155,8 +1177,13 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     const unsigned koff = (unsigned)(ikt * RB);
     if (h & 1) {
       const unsigned s = koff + (h == 3 ? stepA1 : 0u);
+#ifdef VIMA_LAB_NT_A
+      glds16_asm_s_nt(A, offA[0] + s, dst);
+      glds16_asm_s_nt(A, offA[1] + s, dst + 8 * 1024);
+#else
       glds16_asm_s(A, offA[0] + s, dst);
       glds16_asm_s(A, offA[1] + s, dst + 8 * 1024);
+#endif
     } else {
       const unsigned s = koff + (h == 2 ? stepB1 : 0u);
       glds16_asm_s(W, offW[0] + s, dst);
@@ -1174,6 +1201,9 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
 
   int cv = next_valid(blockIdx.x);
   if (cv < 0) return;
+#ifdef VIMA_LAB_SKEW   // timing-only experiment (scripts/micro/gemm_lab): every other CU of an XCD starts VIMA_LAB_SKEW x 8k clocks late
+  if ((blockIdx.x >> 3) & 1) { for (int i = 0; i < VIMA_LAB_SKEW; ++i) __builtin_amdgcn_s_sleep(127); }
+#endif
   iv = cv;
   set_ptrs(iv);
   // prologue: K-tile 0 completely, K-tile 1 up to B1 (its A1 is phase 1's request)
@@ -1911,6 +1941,7 @@ dim3 resident_geometry(GemmDev& d, const GemmArgs& a) {
 int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t st) {
   if (a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || (a.N % 4 != 0 && !a.grp_col)) return -1;
   if (a.ssq_out && a.act != ACT_NONE) return -1;
+  if (a.resT && a.act != ACT_NONE) return -1;   // the kernel applies the bf16 residual only without an activation (launch_t refuses the pair anyway)
   const long long nb = a.batch > 0 ? a.batch : 1;
   const long long maxwg = gemm_res_maxwg(a.tune);
   const long long m32 = (a.M + 31) / 32, m64 = (a.M + 63) / 64, n32 = (a.N + 31) / 32, n64 = (a.N + 63) / 64;
@@ -2151,6 +2182,17 @@ int gemm_dual_ok(const Tuning* t, int M, int N) {
   if (!gemm_grouped_ok(t) || M <= 0 || N <= 0 || N % 4 != 0) return 0;
   if (M <= 32) return 1;
   return (long long)((M + 63) / 64) * ((N + 63) / 64) <= gemm_res_maxwg(t) ? 1 : 0;
+}
+// fp8 ACTIVATIONS (GemmArgs::a8) exist on gemm_pp_kernel<.., F8> only: mirrors, condition for condition, the path launch_t takes
+// for an a8 problem (anything else makes launch_gemm return hipErrorInvalidValue), so that callers can decide BEFORE quantising.
+int gemm_a8_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw) {
+  if (M <= 0 || N <= 0 || K < 256 || K % 256 != 0 || M % TileL::BM != 0 || N % TileL::BN != 0) return 0;
+  if (N % 8 != 0 || lda % 16 != 0 || ldw % 16 != 0) return 0;
+  const int gt = gemm_tile(t);
+  if (!(gt == 0 || gt == 2) || !gemm_persist(t) || gemm_raster(t) != 0 || !gemm_epi(t)) return 0;
+  if (gt == 0 && (M / TileL::BM) * (N / TileL::BN) < 160) return 0;        // `large`: the 256x256 grid fills the chip
+  if (M * lda * 2 >= (1LL << 32) || N * ldw >= (1LL << 32)) return 0;      // 32-bit LDS-DMA offsets (launch_t prices A at 2 bytes)
+  return 1;
 }
 int gemm_grouped_ok(const Tuning* t) {
 #ifdef VIMA_GEMM_LAB

@@ -104,6 +104,7 @@ size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
 int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 int gemm_dual_ok(const Tuning* t, int M, int N);   // the DUAL form (GemmArgs::W2) is available for an [M, N] output with this handle's knobs
+int gemm_a8_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw);   // an fp8-ACTIVATION GEMM (GemmArgs::a8) of this shape is launchable with this handle's knobs
 int gemm_grouped_ok(const Tuning* t);   // the grouped form (GemmArgs::grp_col) is available with this handle's knobs
 
 // ---------------------------------------------------------------- normalisation / elementwise

@@ -42,6 +42,25 @@ int fail(const std::string& m, int code = 1) {
 }  // namespace
 namespace vima {
 int api_fail(const std::string& m) { return fail(m); }   // for the other translation units of the C ABI (comm.hip)
+
+// precision "fp8": freeze the dequantisation scales of a site group from the calibrating pass's max |x|: a non-finite maximum
+// (an inf / NaN activation in the calibrating batch) is REFUSED -- scale = inf would zero every later activation of the site --, a dead site
+// (max 0) gets scale 1, every other site headroom x max / 448. Returns 0, or the failure code with the handle left uncalibrated.
+int fp8_scales_from_amax(const std::vector<float>& am, int headroom_pct, const char* group, std::vector<float>& out) {
+  const float hr = (headroom_pct >= 100 ? headroom_pct : 100) * 0.01f;
+  std::vector<float> sc(am.size());
+  for (size_t i = 0; i < am.size(); ++i) {
+    if (!std::isfinite(am[i])) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "precision fp8: calibration of %s site %zu saw a non-finite activation (max |x| = %g); the scales were NOT frozen -- "
+               "fix the input and call again", group, i, (double)am[i]);
+      return fail(buf);
+    }
+    sc[i] = am[i] > 0.f ? am[i] * hr / 448.0f : 1.0f;
+  }
+  out.swap(sc);
+  return 0;
+}
 }
 namespace {
 
@@ -147,7 +166,7 @@ struct Arena {          // stream-ordered bump allocator; chunks are only releas
   }
 };
 
-struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; int kid = 0; };   // kid: GemmArgs::kernel_id of a GEMM launch
+struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; int kid = 0; int M = 0, N = 0, K = 0; };   // kid: GemmArgs::kernel_id of a GEMM launch (M, N, K: its shape)
 
 }  // namespace
 
@@ -167,7 +186,10 @@ struct VimaHandle {
   std::vector<float> vit8_scale, kv8_scale;
   float *vit8_amax = nullptr, *kv8_amax = nullptr;
   bool fp8_ready = false;
-  std::vector<float> fp8_scale;      // [kT5Layers * 4] dequantisation scales (amax / 448)
+  int fp8_headroom_pct = 125;        // option "fp8_headroom_pct": a site's scale = headroom x (max |x| of the calibrating batch) / 448, so that a later
+                                     // activation up to `headroom` x larger than anything the calibrating batch held still maps below the e4m3 maximum
+                                     // instead of saturating (e4m3 is a floating-point format: headroom costs no relative precision above its subnormals)
+  std::vector<float> fp8_scale;      // [kT5Layers * 4] dequantisation scales (headroom * amax / 448)
   float* fp8_amax = nullptr;         // device, [kT5Layers * 4]
   bool finalized = false;
   int attn_impl = 1;
@@ -686,7 +708,7 @@ struct Run {
     a.kernel_id = &kid;
     int e = launch_gemm(a, h->bf16, st);
     prof_end();
-    if (h->prof && !h->recs.empty()) h->recs.back().kid = kid;
+    if (h->prof && !h->recs.empty()) { ProfRec& r = h->recs.back(); r.kid = kid; r.M = a.M; r.N = a.N; r.K = a.K; }
     if (e) err = fail(std::string("gemm launch failed: ") + hipGetErrorString((hipError_t)e) + " (M=" + std::to_string(a.M) +
                       " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + ")", e);
     return err;
@@ -954,7 +976,13 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
   // precision "fp8": chunks whose GEMMs fit the fp8 kernel (full 256x256 tiles; >= 160 of them in the N = 768 GEMMs of the
   // cls-only last block, M = crops) take fp8 activations once the 16 site scales are calibrated; the first such call calibrates
   auto fits8 = [&](int mc) { return mc % 256 == 0 && (mc / 256) * (kVitW / 256) >= 160; };
-  const bool can8 = h->a8 && h->bf16 && h->stream_T && h->vit_prune_last && fits8(chunk);
+  // ... and only while the handle's knobs leave the fp8-activation kernel reachable (gemm_a8_ok mirrors launch_gemm's eligibility incl. the
+  // 32-bit offset bounds: with gemm_persist = 0, gemm_tile = 1, gemm_raster = 1 ... the stage keeps bf16 activations instead of failing)
+  auto a8ok = [&](int mc) {
+    return gemm_a8_ok(&h->tune, mc, kVitW, kVitW, kVitW, kVitW) && gemm_a8_ok(&h->tune, (long long)mc * 5, 3 * kVitW, kVitW, kVitW, kVitW) &&
+           gemm_a8_ok(&h->tune, (long long)mc * 5, 4 * kVitW, kVitW, kVitW, kVitW) && gemm_a8_ok(&h->tune, (long long)mc * 5, kVitW, 4 * kVitW, 4 * kVitW, 4 * kVitW);
+  };
+  const bool can8 = h->a8 && h->bf16 && h->stream_T && h->vit_prune_last && fits8(chunk) && a8ok(chunk);
   const bool calibrate = can8 && !h->vit8_ready;
   if (calibrate) {
     if (!h->vit8_amax) {
@@ -977,7 +1005,7 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
   for (int r0 = 0; r0 < M; r0 += chunk, ++ci) {
     const int mc = (M - r0) < chunk ? (M - r0) : chunk;
     Run& Rc = (dual && (ci & 1)) ? Rb : R;
-    const int f8mode = (can8 && fits8(mc)) ? (h->vit8_ready ? 2 : 1) : 0;
+    const int f8mode = (can8 && fits8(mc) && a8ok(mc)) ? (h->vit8_ready ? 2 : 1) : 0;
     vit_chunk(Rc, crops, per_view, r0, mc, vb[dual ? (ci & 1) : 0], cat, f8mode, h->vit8_amax, h->vit8_scale.data());
     if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
   }
@@ -986,8 +1014,7 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
     std::vector<float> am(kVitLayers * 4);
     HIPCK(hipMemcpyAsync(am.data(), h->vit8_amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, R.st));
     HIPCK(hipStreamSynchronize(R.st));
-    h->vit8_scale.resize(am.size());
-    for (size_t i = 0; i < am.size(); ++i) h->vit8_scale[i] = am[i] > 0.f ? am[i] / 448.0f : 1.0f;
+    if (int e = fp8_scales_from_amax(am, h->fp8_headroom_pct, "ViT", h->vit8_scale)) return R.err = e;
     h->vit8_ready = true;
     ++h->state_gen;
   }
@@ -1179,7 +1206,13 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   // precision "fp8": fp8 activations when the four GEMM shapes of a layer fit the fp8 kernel (full 256x256 tiles, >= 160 of them for
   // the N = 768 GEMMs) and the scales are calibrated; the first pass of a handle calibrates (fp8w kernels + max |x| per site)
   auto fits8 = [&](int n) { const long long r = (long long)n * L; return n == 0 || (r % 256 == 0 && (r / 256) * (kT5Model / 256) >= 160); };
-  const bool can8 = h->a8 && h->bf16 && h->stream_T && h->t5_fuse_rms && !gemm_splitk_enabled(&h->tune) && fits8(nb[0]) && fits8(nb[1]);
+  auto a8ok = [&](int n) {   // the four GEMM shapes of a layer on the fp8-activation kernel with this handle's knobs (see obj_encode)
+    const long long r = (long long)n * L;
+    return n == 0 || (gemm_a8_ok(&h->tune, r, 3 * kT5Model, kT5Model, kT5Model, kT5Model) && gemm_a8_ok(&h->tune, r, kT5Model, kT5Model, kT5Model, kT5Model) &&
+                      gemm_a8_ok(&h->tune, r, kT5FF, kT5Model, kT5Model, kT5Model) && gemm_a8_ok(&h->tune, r, kT5Model, kT5FF, kT5FF, kT5FF));
+  };
+  const bool can8 = h->a8 && h->bf16 && h->stream_T && h->t5_fuse_rms && !gemm_splitk_enabled(&h->tune) && fits8(nb[0]) && fits8(nb[1]) &&
+                    a8ok(nb[0]) && a8ok(nb[1]);
   const bool run8 = can8 && h->fp8_ready;
   const bool calibrate = can8 && !h->fp8_ready;
   if (calibrate) {
@@ -1251,8 +1284,7 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     std::vector<float> am(kT5Layers * 4);
     HIPCK(hipMemcpyAsync(am.data(), h->fp8_amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, R.st));
     HIPCK(hipStreamSynchronize(R.st));
-    h->fp8_scale.resize(am.size());
-    for (size_t i = 0; i < am.size(); ++i) h->fp8_scale[i] = am[i] > 0.f ? am[i] / 448.0f : 1.0f;
+    if (int e = fp8_scales_from_amax(am, h->fp8_headroom_pct, "T5", h->fp8_scale)) return R.err = e;
     h->fp8_ready = true;
     ++h->state_gen;
   }
@@ -1522,6 +1554,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "op_stream_T") h->op_stream_T = (int)value;
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
+  else if (k == "fp8_headroom_pct") { h->fp8_headroom_pct = value < 100 ? 100 : (int)value; h->fp8_ready = false; h->vit8_ready = false; h->kv8_ready = false; }
   else if (k == "fp8_recalibrate") { h->fp8_ready = false; h->vit8_ready = false; h->kv8_ready = false; }   // precision "fp8": measure the activation scales again
   else return fail("vima_set_option: unknown key " + k);
   return 0;
@@ -1570,6 +1603,30 @@ int vima_prof_read_gemm_kernels(VimaHandle* h, int max_n, int32_t* ids, double* 
       i = it->second;
     }
     ms[i] += t; launches[i] += 1; flops[i] += r.flops; bytes[i] += r.bytes;
+  }
+  return n;
+}
+
+int vima_prof_read_gemm_launches(VimaHandle* h, int max_n, int32_t* ids, int32_t* mnk, float* us) {
+  if (!h || max_n < 0 || (max_n > 0 && (!ids || !mnk))) {
+    (void)fail("vima_prof_read_gemm_launches: bad argument");
+    return -1;
+  }
+  int n = 0;
+  for (auto& r : h->recs) {
+    if (r.cls != 0 && r.cls != 3) continue;
+    if (n < max_n) {
+      ids[n] = r.kid; mnk[3 * n] = r.M; mnk[3 * n + 1] = r.N; mnk[3 * n + 2] = r.K;
+      if (us) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+          (void)fail("vima_prof_read_gemm_launches: event query failed");
+          return -1;
+        }
+        us[n] = t * 1e3f;
+      }
+    }
+    ++n;
   }
   return n;
 }
@@ -1821,7 +1878,8 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
   // one calibrated scale when their shape fits the fp8 kernel; the first such call measures max |prompt + position embedding|
   void* p8 = nullptr;
   float kv_scale = 0.f;
-  if (build_kv && h->a8 && h->bf16 && E % 256 == 0 && rp % 256 == 0 && (long long)(rp / 256) * (2 * E / 256) >= 160 && h->dec[0].kv.ws) {
+  if (build_kv && h->a8 && h->bf16 && E % 256 == 0 && rp % 256 == 0 && (long long)(rp / 256) * (2 * E / 256) >= 160 && h->dec[0].kv.ws &&
+      gemm_a8_ok(&h->tune, rp, 2 * E, E, E, E)) {
     if (!h->kv8_ready) {
       if (!h->kv8_amax) {
         HIPCK(hipMalloc((void**)&h->kv8_amax, sizeof(float)));
@@ -1832,7 +1890,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
       float am = 0.f;
       HIPCK(hipMemcpyAsync(&am, h->kv8_amax, sizeof(float), hipMemcpyDeviceToHost, R.st));
       HIPCK(hipStreamSynchronize(R.st));
-      h->kv8_scale.assign(1, am > 0.f ? am / 448.0f : 1.0f);
+      if (int e = fp8_scales_from_amax(std::vector<float>(1, am), h->fp8_headroom_pct, "prompt K/V", h->kv8_scale)) return R.err = e;
       h->kv8_ready = true;
       ++h->state_gen;
     } else {

@@ -537,6 +537,30 @@ class VIMAPolicy(nn.Module):
                    12: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>>", 15: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 2, true>> (GEGLU pair)",
                    16: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 1, true>> (GEGLU pair)"}
 
+    def _gemm_kernel_name(self, kid: int) -> str:
+        kind, rest = divmod(int(kid), 1000)
+        act, epi = divmod(rest, 10)
+        base = self._GEMM_KINDS.get(kind, f"gemm kind {kind}")
+        if kind == 9:
+            return f"{base}<{act - 1}, {epi}, true>"          # fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
+        if kind == 1:
+            return f"{base}<{act - 1}, {epi}, false>"
+        return f"{base}<{act - 1}, {epi}>" if kind in (2, 3) else f"{base} act {act - 1}"
+
+    def prof_read_gemm_launches(self):
+        """GEMM launches recorded since prof_enable(True), ONE BY ONE in launch order (call BEFORE prof_read / prof_read_ex) ->
+        [{"kernel": rocprofv3 name, "M", "N", "K", "us"}]."""
+        n = self._lib.vima_prof_read_gemm_launches(self._handle, 0, None, None, None)
+        if n < 0:
+            _lib.check(1)
+        ids = (ctypes.c_int32 * max(n, 1))()
+        mnk = (ctypes.c_int32 * (3 * max(n, 1)))()
+        us = (ctypes.c_float * max(n, 1))()
+        if self._lib.vima_prof_read_gemm_launches(self._handle, n, ids, mnk, us) < 0:
+            _lib.check(1)
+        return [{"kernel": self._gemm_kernel_name(ids[i]), "M": int(mnk[3 * i]), "N": int(mnk[3 * i + 1]), "K": int(mnk[3 * i + 2]),
+                 "us": float(us[i])} for i in range(n)]
+
     def prof_read_gemm_kernels(self):
         """GEMM launches recorded since prof_enable(True), grouped by the kernel the launcher chose (call BEFORE prof_read /
         prof_read_ex, which reset the records) -> {kernel name as rocprofv3 prints it: {ms, launches, flops, bytes}}."""
@@ -551,15 +575,7 @@ class VIMAPolicy(nn.Module):
             _lib.check(1)
         out = {}
         for i in range(k):
-            kind, rest = divmod(int(ids[i]), 1000)
-            act, epi = divmod(rest, 10)
-            base = self._GEMM_KINDS.get(kind, f"gemm kind {kind}")
-            if kind == 9:
-                name = f"{base}<{act - 1}, {epi}, true>"          # fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
-            elif kind == 1:
-                name = f"{base}<{act - 1}, {epi}, false>"
-            else:
-                name = f"{base}<{act - 1}, {epi}>" if kind in (2, 3) else f"{base} act {act - 1}"
+            name = self._gemm_kernel_name(ids[i])
             out[name] = {"ms": ms[i], "launches": int(ln[i]), "flops": fl[i], "bytes": by[i]}
         return out
 

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .synthetic import MapDict
+from .containers import MapDict
 
 
 def _dev_tensor(x, device, dtype=None):
