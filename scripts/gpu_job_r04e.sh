@@ -1,0 +1,12 @@
+# Round 4, job e: phase ablations (timing only) and real variants of the T5 flash attention kernel, one library per variant (build_ablate/)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r04e}
+cd $R
+OUT=$O/${TAG}_attn.txt; : > $OUT
+for v in base $2; do
+  if [ $v = base ]; then unset VIMA_HIP_LIB; else export VIMA_HIP_LIB=$R/build_ablate/libvima_hip_$v.so; fi
+  echo "== $v" >> $OUT
+  timeout 120 python scripts/attn_micro.py 256 12 512 64 10 2>&1 | grep "attn mode" >> $OUT
+  timeout 120 python scripts/attn_micro.py 256 12 1024 64 5 2>&1 | grep "attn mode" >> $OUT
+done
+unset VIMA_HIP_LIB
+cat $OUT

@@ -39,13 +39,17 @@ __device__ __forceinline__ void ld8(const float* p, float* f) {
 }
 
 // q: the query's 32 values; krow(j) / vrow(j): pointer to the 32 values of key / value row j of this head; o: the 32 outputs
-template <typename T, typename KR, typename VR>
-__device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, VR vrow, float (&o)[32]) {
+// co[c / 8]: element offset of the head's 8-value chunk c / 8 inside its 32-value row segment -- {0, 8, 16, 24} everywhere except in
+// vit_attn_lds_kernel, whose LDS image stores the four 16-byte chunks of a head permuted (bank conflicts); the VALUES and the order of
+// the arithmetic do not depend on it.
+struct ChunkId { __device__ __forceinline__ int operator[](int i) const { return i * 8; } };
+template <typename T, typename KR, typename VR, typename CO = ChunkId>
+__device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, VR vrow, float (&o)[32], CO co = CO()) {
 #pragma clang fp contract(off)
   constexpr int D = 32;
   float q[D];
 #pragma unroll
-  for (int c = 0; c < D; c += 8) ld8(qp + c, q + c);
+  for (int c = 0; c < D; c += 8) ld8(qp + co[c >> 3], q + c);
   const float scale = 0.17677669529663687f;  // 1/sqrt(32)
   float s[8];
   float mx = -INFINITY;
@@ -58,7 +62,7 @@ __device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, 
 #pragma unroll
       for (int c = 0; c < D; c += 8) {
         float v[8];
-        ld8(kp + c, v);
+        ld8(kp + co[c >> 3], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) d = __builtin_fmaf(q[c + e], v[e], d);
       }
@@ -83,7 +87,7 @@ __device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, 
 #pragma unroll
       for (int c = 0; c < D; c += 8) {
         float v[8];
-        ld8(vp + c, v);
+        ld8(vp + co[c >> 3], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[c + e] = __builtin_fmaf(pj, v[e], o[c + e]);
       }
@@ -128,6 +132,12 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
 // of HBM data (4.2 TB/s). Here a workgroup copies the contiguous q|k|v rows of TWO crops (10 x 4 608 B) into LDS once with 16-byte
 // LDS-DMA requests and its 240 (crop, query, head) threads read them from there with ds_read_b128; three workgroups per CU keep
 // 135 KB of loads in flight (5.4 TB/s). Same per-head body as the other two kernels: bit-identical results.
+// Round 4: consecutive lanes are consecutive HEADS, 64 bytes apart, so the 16 lanes of a ds_read_b128 group hit every bank four times (SQ
+// counters: LDS conflict ratio 0.67). The image is therefore stored with the four 16-byte chunks of head h permuted, position x holds
+// chunk x ^ ((h >> 2) & 3) (applied on the SOURCE address of the LDS-DMA, which is per lane; the destination stays lane-linear), and read
+// back through the same XOR: the 16 lanes of a group (heads a + 4 b: every 64-byte bank quarter a four times, with four different b) then
+// touch 16 distinct 16-byte slots of the bank row (K / V reads conflict-free, the query reads of lanes on different rows 2-way: ratio 0.30).
+// The kernel time did not move (92 us): it reads 415 MB and WRITES 138 MB per launch = 6.0 TB/s, the copy rate of this chip (6.3 TB/s).
 constexpr int VA_S = 5, VA_W = 768, VA_H = 24, VA_ROWB = 3 * VA_W * 2;   // bytes per qkv row
 __global__ __launch_bounds__(256) void vit_attn_lds_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int M,
                                                             uint8_t* out8, float inv8) {
@@ -140,9 +150,11 @@ __global__ __launch_bounds__(256) void vit_attn_lds_kernel(const bf16_t* __restr
   const char* src = reinterpret_cast<const char*>(qkv) + m0 * VA_S * VA_ROWB;
 #pragma unroll
   for (int it = 0; it < (2 * VA_S * VA_ROWB / 16 + 255) / 256; ++it) {
-    const int c = it * 256 + tid;
+    const int c = it * 256 + tid;                     // LDS chunk position (lane-linear destination)
+    const int pr = c % (VA_ROWB / 16);                // position inside its qkv row: [q | k | v] x 24 heads x 4 chunks
+    const int g = c ^ (((pr % (VA_W / 8)) >> 4) & 3);   // global chunk: x ^ ((h >> 2) & 3), h = (pr % 96) / 4
     if (c < chunks)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)c * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)g * 16),
                                        (__attribute__((address_space(3))) void*)(va_smem + (it * 256 + w * 64) * 16), 16, 0, 0);
   }
   __syncthreads();
@@ -151,8 +163,9 @@ __global__ __launch_bounds__(256) void vit_attn_lds_kernel(const bf16_t* __restr
   const int i = rem / VA_H, h = rem % VA_H;
   const bf16_t* base = reinterpret_cast<const bf16_t*>(va_smem) + cl * VA_S * (3 * VA_W);
   float o[D];
+  struct ChunkSw { int b; __device__ __forceinline__ int operator[](int i) const { return (i ^ b) * 8; } };
   vit_head_attention<bf16_t>(base + i * (3 * VA_W) + h * D, VA_S, [&](int j) { return base + j * (3 * VA_W) + VA_W + h * D; },
-                             [&](int j) { return base + j * (3 * VA_W) + 2 * VA_W + h * D; }, o);
+                             [&](int j) { return base + j * (3 * VA_W) + 2 * VA_W + h * D; }, o, ChunkSw{(h >> 2) & 3});
   const long long mi = (m0 + cl) * VA_S + i;
   vit_store_head<bf16_t>(o, out + mi * VA_W + h * D, out8 ? out8 + mi * VA_W + h * D : nullptr, inv8);
 }
