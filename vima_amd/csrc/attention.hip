@@ -449,7 +449,13 @@ __device__ __forceinline__ int kswz(int r, int c) {
   return c ^ ((r >> 2) & 3);                // 64-B rows, 4 chunks
 }
 
-// (phase ablations of this kernel -- timing only, wrong results -- live in scripts/ablate/attn_ablate.patch)
+// (phase ablations of this kernel -- timing only, wrong results -- live in scripts/ablate/attn_ablate.patch and attn_persistent_r04.patch)
+#ifndef VIMA_ATTN_NSTG1
+#define VIMA_ATTN_NSTG1 2   // ring stages with 32 queries per wave (3 measured 15 % slower: profiles/r04_attention_ablation.txt)
+#endif
+#ifndef VIMA_ATTN_NSTG2
+#define VIMA_ATTN_NSTG2 3   // ... with 64 queries per wave (option attn_qg = 2)
+#endif
 // QG = query groups of 32 per wave. QG = 2 (option attn_qg = 2): a wave owns 64 queries, i.e. a workgroup 256; every K / V
 // fragment read from LDS feeds TWO MFMAs (one per group), and the staging of a key tile (global loads, LDS stores, barrier) is
 // amortised over twice the queries; the softmax VALU work per query is unchanged. Costs registers (two waves per SIMD).
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   // K / V tiles are staged by LDS-DMA into a ring of NSTG stages; NSTG - 1 tiles are in flight while one is multiplied. (Round 3:
   // the register-staged double buffer spent 18 % of a key tile issuing the next tile's loads -- address arithmetic and four 16-byte
   // loads per lane -- and 8 % writing them to LDS; per-phase shader-clock stamps, scripts/attn_micro.py STAMPS=1.)
-  constexpr int NSTG = QG > 1 ? 3 : 2;                         // 64 queries per wave run two workgroups per CU: room for three stages
+  constexpr int NSTG = QG > 1 ? VIMA_ATTN_NSTG2 : VIMA_ATTN_NSTG1;   // 64 queries per wave run two workgroups per CU: room for three stages
   constexpr int NI = D / 32;                                   // 1-KiB DMA instructions per wave and tile for K, and as many for V
   char* ks_base = smem4;                                       // [NSTG][64][ROWB]
   char* vt_base = smem4 + NSTG * KS_BYTES;                            // [NSTG] x V image (sub-tiled, see vsub_off)
@@ -1084,7 +1090,7 @@ template <int D, int MODE, int QG>
 static int launch_mfma4_qg(const AttnDev& d, const AttnArgs& a, hipStream_t st) {
   const int nt = (a.Lk + 63) / 64;
   const int nq = (a.Lq + 128 * QG - 1) / (128 * QG);
-  constexpr int NSTG = QG > 1 ? 3 : 2;   // as in the kernel
+  constexpr int NSTG = QG > 1 ? VIMA_ATTN_NSTG2 : VIMA_ATTN_NSTG1;   // as in the kernel
   const size_t sh = NSTG * (64 * D * 2) + NSTG * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 + (size_t)((nt + 3) & ~3) * 4 +
                     (MODE == ATTN_T5 ? (size_t)(nq * 128 * QG + nt * 64) * 4 : 0);
   if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
