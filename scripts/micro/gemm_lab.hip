@@ -95,6 +95,8 @@ int main(int argc, char** argv) {
   const size_t out_bytes = (size_t)M * N * (epi == 3 ? 4 : 2);
   std::vector<void*> outs(vars.size());
   for (size_t i = 0; i < vars.size(); ++i) CK(hipMalloc(&outs[i], out_bytes));
+  float* ssq = nullptr;
+  if (getenv("SSQ")) CK(hipMalloc(&ssq, (size_t)M * (N / 32) * 4));
   long long* dbg = nullptr;
   const int nblk = ((M + 255) / 256 + 7) / 8 * 8 * ((N + 255) / 256);
   if (stamps) { CK(hipMalloc(&dbg, (size_t)nblk * 40 * 8)); }
@@ -125,7 +127,7 @@ int main(int argc, char** argv) {
     if (vars[vi].name == "fp8") { a.A = A8; a.W = W8; a.a8 = 1; a.w8 = 1; a.wscale = wsc; a.ascale = asc; }
     a.tune = &vars[vi].t;
     if (epi == 1) { a.outT = outs[vi]; a.ldT = N; }
-    else if (epi == 4) { a.outT = outs[vi]; a.ldT = N; a.resT = outs[vi]; a.ldresT = N; }   // in place, like the model's stream
+    else if (epi == 4) { a.outT = outs[vi]; a.ldT = N; a.resT = outs[vi]; a.ldresT = N; a.ssq_out = ssq; }   // in place, like the model's stream (SSQ=1: + RMS partials)
     else if (epi == 3) { a.out32 = (float*)outs[vi]; a.ld32 = N; a.res = (float*)outs[vi]; a.ldres = N; }
     else if (epi == 2) { a.outT = outs[vi]; a.ldT = N; a.mul = res0; a.ldmul = N; }
     return a;
