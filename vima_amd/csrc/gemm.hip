@@ -711,6 +711,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
     }
   // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
   constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4;
+  static_assert(WIDE8 || AUX, "the fp32-output epilogue (EPI 3) stores through emit_stores");
   const char* auxp = nullptr;
   long long aux_ld = 0;                                         // bytes per row
   if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
@@ -730,6 +731,33 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
     }
   };
   if (AUX) issue_aux(0, aux[0]);
+  // Epilogues with a per-row operand (AUX) hold a slab's finished values in registers and issue its STORES one slab late, behind the next slab's
+  // operand wait -- see the note at that wait. h_*: the held slab (which members are live depends on EPI; the others are dead code).
+  uint4 h_o[NIT];
+  uint2 h_o8[NIT];
+  float4 h_v[NIT];
+  float h_sq[NIT];
+  auto emit_stores = [&](int sl) {   // the stores of slab sl from the held registers (compile-time sl after unrolling)
+    const int mi = sl / NI, ni = sl % NI;
+    const int n = ncol0 + ni * 32;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const long long m = mrow0 + mi * 32 + it * RPI;
+      if constexpr (WIDE8) {
+#ifdef VIMA_LAB_NOSTORE   // timing-only ablation: the output tile is never written
+        asm volatile("" ::"v"(h_o[it].x), "v"(h_o[it].y), "v"(h_o[it].z), "v"(h_o[it].w));
+#else
+        if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = h_o[it];
+#endif
+        if (EPI == 4 && p.out8) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = h_o8[it];
+        if (EPI == 4 && ssq_out && (elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = h_sq[it];
+      } else {
+        store4(out32 + m * p.ld32 + n, h_v[it]);
+        if (outT) store4(outT + m * p.ldT + n, h_v[it]);
+        if (ssq_out && (elane & 7) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = h_sq[it];   // plain store: deterministic
+      }
+    }
+  };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const float rsc = rscv[mi];
@@ -744,25 +772,30 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
         if constexpr (HAS_RS) { v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc; }
         *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = v;
       }
-      // ---- prefetch the next slab's per-row operand, then wait for this slab's (issued one slab ago). Younger VMEM
-      // operations at that point: the stores of the previous slab (EPI 2: exactly NIT; EPI 3: at least NIT) and the NIT
-      // loads just issued -- a smaller count only waits for a few more (older) stores. DO NOT raise the count where an epilogue
-      // issues more stores per slab (EPI 4 with RMS partials: 2 NIT): the C++ stores are not pinned against these asm waits,
-      // hipcc may sink some of them below the wait, and vmcnt(3 NIT) then returns before the operand has landed (measured in
-      // round 4: 2 % of the output elements wrong, profiles/r04_gemm_epilogue_ablation.txt); 2 NIT has the margin.
+      // ---- prefetch the next slab's per-row operand, wait for this slab's (issued one slab ago), THEN issue the previous slab's stores.
+      // gfx950 retires loads in order and stores in order, but NOT loads and stores against each other (measured in round 4,
+      // profiles/r04_gemm_epilogue_ablation.txt: counting the previous slab's stores as "younger than these loads" gave 2-5 % wrong output
+      // elements -- store acknowledgements overtake older loads). A counted wait for LOADS may therefore only count younger LOADS: vmcnt(NIT)
+      // (the NIT loads just issued for the next slab; 0 behind the last slab) is the largest count that guarantees all NIT loads of this slab,
+      // whatever the stores do. It also waits for every store still in flight -- which is why a slab's stores are issued one slab LATE, from
+      // registers (emit_stores): the stores in flight at this wait are those of slab sl - 2, issued a whole slab ago, not those of the slab just
+      // finished. Rounds 2-3 stored right away and waited vmcnt(2 NIT) here: correct only while the youngest store was still unacknowledged
+      // whenever a load was -- a timing margin that was never seen to fail (bit-exact cross-checks over 1e8-4e8 elements per run), but no
+      // guarantee. Cost of the guarantee, same box, pp kernel: T5 o +2 %, wo +1 %, fp32-residual and GEGLU epilogues -2...+3 %. The "memory"
+      // clobber keeps hipcc from moving the C++ stores across the wait.
       if (AUX) {
         if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
-        constexpr int kYoungLoads = NIT;
         f32x4_t(&a)[NIT] = aux[sl & 1];
 #ifndef VIMA_LAB_NORES   // (the timing-only ablation has nothing to wait for)
-        if (sl == 0 || sl + 1 == NSLAB) {
-          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(kYoungLoads));
-          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(kYoungLoads));
-        } else {
-          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(2 * kYoungLoads));
-          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(2 * kYoungLoads));
+        if (sl + 1 < NSLAB) {
+          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(NIT) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(NIT) : "memory");
+        } else {   // last slab: no younger loads
+          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]) : : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : : "memory");
         }
 #endif
+        if (sl > 0) emit_stores(sl - 1);
       }
       // ---- (2) read back and finish
       const int n = ncol0 + ni * 32;
@@ -802,6 +835,8 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
         if constexpr (WIDE8) {
           uint4 o;
           o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
+          if constexpr (AUX) h_o[it] = o;
+          else {
 #ifdef VIMA_LAB_NOSTORE   // timing-only ablation: the output tile is never written
           asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
 #elif defined(VIMA_LAB_NT_ST)   // experiment: non-temporal output stores (the output is never re-read by this kernel)
@@ -811,6 +846,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
 #else
           if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
 #endif
+          }
           if ((EPI == 1 || EPI == 4) && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
             const float q = p.out8_inv;
             auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); };
@@ -819,25 +855,26 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
             w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[0].z * q), cl(v[0].w * q), w0, true);
             w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[1].x * q), cl(v[1].y * q), w1, false);
             w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v[1].z * q), cl(v[1].w * q), w1, true);
-            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = make_uint2((unsigned)w0, (unsigned)w1);
+            if constexpr (AUX) h_o8[it] = make_uint2((unsigned)w0, (unsigned)w1);
+            else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = make_uint2((unsigned)w0, (unsigned)w1);
           }
           if (EPI == 4 && ssq_out) {   // RMS partials of the stored (rounded) stream: 4 lanes hold the 32 columns of a slab row
             float sq = sumsq8_bf16(o);
             sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
-            if ((elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;
+            h_sq[it] = sq;
           }
-        } else {
-          store4(out32 + m * p.ld32 + n, v[0]);
-          if (outT) store4(outT + m * p.ldT + n, v[0]);
+        } else {   // EPI 3 (always AUX): fp32 (+ operand-type) output, stored by emit_stores
+          h_v[it] = v[0];
           if (ssq_out) {   // the row's 8 column groups of this 32-column slab: butterfly, one partial per row and slab
             float sq = sumsq4(v[0]);
             sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-            if ((elane & 7) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = sq;   // plain store: deterministic
+            h_sq[it] = sq;
           }
         }
       }
     }
   }
+  if (AUX) emit_stores(MI * NI - 1);
 }
 
 template <int ACT, int EPI, bool W8>
@@ -1582,8 +1619,10 @@ __global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const Gemm
           f32x4_t(&a)[NIT] = aux[sl & 1];
           // the bias loads of this column group (mi == 0) sit between the prefetch and this wait: they are older than the
           // prefetch of the NEXT slab, so the same counts cover them
-          if (sl == 0 || sl + 1 == NSLAB) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(NIT));
-          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(2 * NIT));
+          // loads-only count (see tile_epilogue_256_impl: loads and stores do not retire in order against each other); this opt-in kernel
+          // issues a slab's stores right away, so the wait also covers every store issued so far
+          if (sl + 1 < NSLAB) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(NIT) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]) : : "memory");
         }
         const int n = ncol0 + ni * 32;
 #pragma unroll
