@@ -477,6 +477,48 @@ def test_linear_pingpong_is_bit_identical(M, N, K, act, mode):
         pol.set_option("op_bf16_out", 0)
         pol.set_option("op_stream_T", 0)
 
+@pytest.mark.parametrize("M,N,K,act,mode", [(131072, 768, 768, 0, "stream"), (65536, 768, 3072, 0, "stream"), (65536, 768, 768, 0, "res32"),
+                                             (32768, 3072, 768, 2, "gate")])
+def test_persistent_epilogue_under_full_load_matches_the_one_tile_kernel_bitwise(M, N, K, act, mode):
+    """Round 4: gfx950 does not retire loads and stores in issue order against each other, so the persistent kernels' epilogues with a per-row
+    operand (bf16 / fp32 residual, GEGLU gate) wait for younger LOADS only and issue a slab's stores one slab late. The failure mode of a wrong
+    count is a slab finished with an operand that has not landed yet, and it only shows when every CU runs its epilogue at once -- so: the
+    benchmark's own shapes at (nearly) full size, several tiles per CU, repeated, bit for bit against the one-tile-per-workgroup kernel, whose
+    epilogue takes its operands with compiler-tracked loads."""
+    pol = bare_policy("bf16")
+    pol.set_option("op_bf16_out", 0 if mode == "res32" else 1)
+    pol.set_option("op_stream_T", 1 if mode == "stream" else 0)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g, device="cuda")
+        W = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+        b = torch.randn(N, generator=g, device="cuda")
+        r = torch.randn(M, N, generator=g, device="cuda") * 3.0 if mode in ("stream", "res32") else None
+        mul = torch.randn(M, N, generator=g, device="cuda") if mode == "gate" else None
+        out = torch.empty(M, N, device="cuda")
+
+        def run():
+            _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(A), ptr(W), ptr(b), ptr(mul), ptr(r), M, N, K, act, ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            return out.clone()
+
+        pol.set_option("gemm_persist", 0)          # one 256x256 tile per workgroup (gemm_kernel)
+        ref = run()
+        pol.set_option("gemm_persist", 1)
+        for pp in (1, 0):                          # ping-pong and round-2 persistent kernels share the epilogue
+            pol.set_option("gemm_pp", pp)
+            for _ in range(3):
+                got = run()
+                bad = int((got != ref).sum())
+                assert bad == 0, f"gemm_pp={pp}: {bad} of {got.numel()} elements differ from the one-tile kernel"
+        assert bool(torch.isfinite(ref).all())
+    finally:
+        pol.set_option("gemm_pp", 1)
+        pol.set_option("gemm_persist", 1)
+        pol.set_option("op_bf16_out", 0)
+        pol.set_option("op_stream_T", 0)
+
+
 @pytest.mark.parametrize("M,N,K,act,stream", [(16384, 768, 768, 0, 1), (16384, 768, 768, 0, 0), (16384, 2304, 128, 0, 0), (16384, 3072, 768, 3, 0),
                                               (24576, 1536, 3072, 1, 0), (32768, 768, 3072, 0, 1)])
 def test_linear_wide_tile_is_bit_identical(M, N, K, act, stream):
