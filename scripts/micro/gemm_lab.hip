@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
     a.tune = &vars[vi].t;
     if (epi == 1) { a.outT = outs[vi]; a.ldT = N; }
     else if (epi == 4) { a.outT = outs[vi]; a.ldT = N; a.resT = outs[vi]; a.ldresT = N; a.ssq_out = ssq; }   // in place, like the model's stream (SSQ=1: + RMS partials)
-    else if (epi == 3) { a.out32 = (float*)outs[vi]; a.ld32 = N; a.res = (float*)outs[vi]; a.ldres = N; }
+    else if (epi == 3) { a.out32 = (float*)outs[vi]; a.ld32 = N; if (!getenv("NORES3")) { a.res = (float*)outs[vi]; a.ldres = N; } }   // NORES3=1: fp32 output without a residual
     else if (epi == 2) { a.outT = outs[vi]; a.ldT = N; a.mul = res0; a.ldmul = N; }
     return a;
   };

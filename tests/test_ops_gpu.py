@@ -478,7 +478,7 @@ def test_linear_pingpong_is_bit_identical(M, N, K, act, mode):
         pol.set_option("op_stream_T", 0)
 
 @pytest.mark.parametrize("M,N,K,act,mode", [(131072, 768, 768, 0, "stream"), (65536, 768, 3072, 0, "stream"), (65536, 768, 768, 0, "res32"),
-                                             (32768, 3072, 768, 2, "gate")])
+                                             (32768, 3072, 768, 2, "gate"), (65536, 768, 768, 0, "out32")])
 def test_persistent_epilogue_under_full_load_matches_the_one_tile_kernel_bitwise(M, N, K, act, mode):
     """Round 4: gfx950 does not retire loads and stores in issue order against each other, so the persistent kernels' epilogues with a per-row
     operand (bf16 / fp32 residual, GEGLU gate) wait for younger LOADS only and issue a slab's stores one slab late. The failure mode of a wrong
@@ -486,7 +486,7 @@ def test_persistent_epilogue_under_full_load_matches_the_one_tile_kernel_bitwise
     benchmark's own shapes at (nearly) full size, several tiles per CU, repeated, bit for bit against the one-tile-per-workgroup kernel, whose
     epilogue takes its operands with compiler-tracked loads."""
     pol = bare_policy("bf16")
-    pol.set_option("op_bf16_out", 0 if mode == "res32" else 1)
+    pol.set_option("op_bf16_out", 0 if mode in ("res32", "out32") else 1)     # out32: fp32 output WITHOUT a residual (the ViT's patch-embed GEMM)
     pol.set_option("op_stream_T", 1 if mode == "stream" else 0)
     try:
         g = torch.Generator(device="cuda").manual_seed(M + N + K)

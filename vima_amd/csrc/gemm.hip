@@ -712,6 +712,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   // per-row operand of slab s = mi * NI + ni, row group it: 16 bytes per lane (8 bf16 gate values / 4 fp32 residuals)
   constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4;
   static_assert(WIDE8 || AUX, "the fp32-output epilogue (EPI 3) stores through emit_stores");
+  const bool aux_on = AUX && !(EPI == 3 && p.res == nullptr);   // EPI 3 also serves fp32 outputs WITHOUT a residual (kernel argument: wave-uniform)
   const char* auxp = nullptr;
   long long aux_ld = 0;                                         // bytes per row
   if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
@@ -730,7 +731,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
 #endif
     }
   };
-  if (AUX) issue_aux(0, aux[0]);
+  if (aux_on) issue_aux(0, aux[0]);
   // Epilogues with a per-row operand (AUX) hold a slab's finished values in registers and issue its STORES one slab late, behind the next slab's
   // operand wait -- see the note at that wait. h_*: the held slab (which members are live depends on EPI; the others are dead code).
   uint4 h_o[NIT];
@@ -784,6 +785,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
       // guarantee. Cost of the guarantee, same box, pp kernel: T5 o +2 %, wo +1 %, fp32-residual and GEGLU epilogues -2...+3 %. The "memory"
       // clobber keeps hipcc from moving the C++ stores across the wait.
       if (AUX) {
+       if (aux_on) {
         if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
         f32x4_t(&a)[NIT] = aux[sl & 1];
 #ifndef VIMA_LAB_NORES   // (the timing-only ablation has nothing to wait for)
@@ -795,6 +797,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : : "memory");
         }
 #endif
+       }
         if (sl > 0) emit_stores(sl - 1);
       }
       // ---- (2) read back and finish
@@ -829,8 +832,10 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           v[1].z += __uint_as_float(g3 << 16); v[1].w += __uint_as_float(g3 & 0xffff0000u);
         }
         if constexpr (EPI == 3) {        // + residual: 4 fp32 values
-          const f32x4_t r4 = aux[sl & 1][it];
-          v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
+          if (aux_on) {
+            const f32x4_t r4 = aux[sl & 1][it];
+            v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
+          }
         }
         if constexpr (WIDE8) {
           uint4 o;
@@ -907,7 +912,7 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
 // wave, XOR-swizzled: conflict-free for ds_write_b128 and both read-back shapes), so both ring stages stay free.
 // EPI specialises the epilogue at compile time (fewer live scalars / registers than the all-runtime form, which spilled):
 //   (0 = every feature a runtime flag: not instantiated) 1 bf16-only output, optional bias / fused-RMSNorm row scale
-//   2 bf16-only output x gate (`mul`: GEGLU)      3 residual add with fp32 (+ optional bf16) output, optional RMS partials
+//   2 bf16-only output x gate (`mul`: GEGLU)      3 fp32 (+ optional bf16) output, with or without an fp32 residual, optional RMS partials
 //   4 residual stream carried in bf16 (`resT`): out = bf16(acc + bias + bf16 residual), optional RMS partials of the stored values
 template <int ACT, int EPI, bool W8 = false>
 __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(const GemmDev p) {
@@ -1801,7 +1806,7 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   if (a.rb == 0) {
     if (d.wide8 && !a.mul && !a.res && !a.resT && !a.ssq_out) epi = 1;
     else if (d.wide8 && a.mul && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
-    else if (!d.wide8 && a.res && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;
+    else if (!d.wide8 && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;   // fp32 (+ operand-type) output, with or without a residual
     else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
   }
   if (a.resT && epi != 4) return -1;   // one-tile-per-workgroup kernel
@@ -1873,7 +1878,7 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
   if (a.rb == 0) {
     if (d.wide8 && !a.mul && !a.res && !a.resT && !a.ssq_out) epi = 1;
     else if (d.wide8 && a.mul && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
-    else if (!d.wide8 && a.res && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;
+    else if (!d.wide8 && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;   // fp32 (+ operand-type) output, with or without a residual
     else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
   }
   if (a.resT && epi != 4) return -1;
@@ -2162,7 +2167,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
         a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
         (long long)a.N * a.ldw * (long long)esw < (1LL << 32)) {
-      const int epi_id = a.resT ? 4 : (a.res ? 3 : (a.mul ? 2 : 1));
+      const int epi_id = a.resT ? 4 : ((a.res || a.out32) ? 3 : (a.mul ? 2 : 1));
       if (gemm_pp(a.tune) || a.a8) {
         const int e = launch_pp(d, a, st);
         if (e >= 0) { if (a.kernel_id) *a.kernel_id = (a.a8 ? 9000 : 1000) + (a.act + 1) * 10 + epi_id; return e; }
