@@ -273,8 +273,9 @@ int vima_t5_bucket(int relative_position);
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass
  *   test / instrumentation:  "op_bf16_out", "op_stream_T" (route vima_op_linear through the bf16-output / bf16-residual
- *                            epilogues; op_stream_T also feeds vima_op_layernorm a bf16 input), "gemm_dbg_ptr", "attn_dbg_ptr"
- *                            (device buffers for shader-clock stamps, 0 = off)
+ *                            epilogues; op_stream_T also feeds vima_op_layernorm a bf16 input), "op_bias_far" (vima_op_attention, T5 mode: promise
+ *                            that the relbias table is constant from that |key - query| on, as the bucketed T5 table is from 91; 0 = no promise),
+ *                            "gemm_dbg_ptr", "attn_dbg_ptr" (device buffers for shader-clock stamps, 0 = off)
  * Process-wide A/B switches read once from the environment (results do not depend on them beyond fp32 summation order inside
  * a LayerNorm row): VIMA_LN_ROWS2=0 (one-wave-per-row LayerNorm instead of the half-wave kernel), VIMA_VIT_ATTN_LDS=0 (per-thread
  * ViT attention instead of the LDS-staged kernel; identical bits), VIMA_GEMM_* (defaults of the GEMM options above),

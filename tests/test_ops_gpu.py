@@ -391,6 +391,44 @@ def test_attention(prec, impl, mode, B, H, Lq, Lk, D):
     assert max_rel(out, ref) < (1.5e-2 if prec == "bf16" else 1e-5)
 
 
+@pytest.mark.parametrize("B,H,L,D,qg", [(2, 12, 512, 64, 1), (1, 3, 1030, 64, 2), (2, 4, 300, 32, 1), (1, 12, 200, 64, 1)])
+def test_t5_attention_constant_bias_beyond_the_last_bucket(B, H, L, D, qg):
+    """Round 4: the bucketed T5 bias table is constant from |key - query| = 91 on; with that promise (AttnArgs::bias_far, here the test
+    option op_bias_far) key tiles wholly beyond it take the constant as a scalar instead of per-score LDS reads. Same values, same arithmetic:
+    the outputs must be IDENTICAL to the run without the promise (and agree with torch); ragged sizes, masked keys, both wave geometries."""
+    pol = bare_policy("bf16")
+    lib = pol._lib
+    g = torch.Generator().manual_seed(L + D)
+    q = torch.randn(B, L, H, D, generator=g) * 0.4
+    k = torch.randn(B, L, H, D, generator=g) * 0.4
+    v = torch.randn(B, L, H, D, generator=g)
+    kmask = torch.rand(B, L, generator=g) > 0.1
+    kmask[:, 0] = True
+    emb = torch.randn(32, H, generator=g)                                  # relative_attention_bias.weight [buckets, heads]
+    delta = torch.arange(-(L - 1), L)
+    bucket = torch.tensor([lib.vima_t5_bucket(int(d)) for d in delta.tolist()])
+    relbias = emb[bucket].T.contiguous()                                   # [H, 2L - 1], index (j - i) + L - 1
+    far = next(n for n in range(1, L) if bool((bucket[L - 1 + n:] == bucket[-1]).all()) and bool((bucket[:L - n] == bucket[0]).all()))
+    assert far == 91 or L <= 91
+    ref = attn_ref(bf(q), bf(k), bf(v), kmask, relbias, 1.0, 0)
+    qd, kd, vd, md, rd = q.cuda(), k.cuda(), v.cuda(), kmask.cuda(), relbias.cuda()
+    pol.set_option("attn_qg", qg)
+    outs = []
+    try:
+        for promise in (0, far):
+            pol.set_option("op_bias_far", promise)
+            out = torch.full((B, L, H, D), float("nan"), device="cuda")
+            _lib.check(lib.vima_op_attention(pol._handle, ptr(qd), ptr(kd), ptr(vd), ptr(md), ptr(rd), B, H, L, L, D, 1.0, 0, 1, ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        pol.set_option("op_bias_far", 0)
+        pol.set_option("attn_qg", 1)
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
+    assert max_rel(outs[1], ref) < 1.5e-2
+
+
 @pytest.mark.parametrize("mode,B,H,Lq,Lk,D", [(0, 1, 12, 300, 300, 64), (0, 2, 3, 1030, 1030, 64), (1, 2, 24, 300, 520, 32), (1, 1, 4, 256, 64, 64),
                                              (0, 1, 2, 257, 257, 32)])
 @pytest.mark.parametrize("qg", [1, 2])

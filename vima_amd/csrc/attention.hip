@@ -197,6 +197,7 @@ struct AttnDev {
   void* out; int ldo;
   const uint8_t* kmask;
   const float* relbias;
+  int bias_far;   // see AttnArgs::bias_far (0 = no promise)
   int B, H, Lq, Lk;
   float scale;
   int mode;
@@ -522,6 +523,12 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     for (int j = 0; j < 64; ++j) f |= (madd[tid * 64 + j] != 0.0f) ? 1 : 0;
     tflag[tid] = f;
   }
+  // T5 with a table that is constant beyond +-bias_far (AttnArgs::bias_far): a key tile ALL of whose (key - query) lie beyond it for every query of
+  // this WAVE takes the constant as one scalar operand instead of 32 per-score LDS reads (16 ds_read2_b32 + their waits: 7 % of the tile's issue
+  // slots, profiles/r04_attention_ablation.txt: "nobias"); 43 % of the (wave, tile) pairs at L = 512, 69 % at L = 1024. Same values, same arithmetic.
+  const int far = MODE == ATTN_T5 ? p.bias_far : 0;
+  const float cfar_pos = far > 0 ? btab[boff + far] : 0.0f, cfar_neg = far > 0 ? btab[boff - far] : 0.0f;
+  const int qw0 = qblk * QB + w * (32 * QG), qw1 = qw0 + 32 * QG - 1;   // this wave's queries (wave-uniform)
 
   bf16x8_t qf[QG][KD];
   f32x16_t ot[QG][OT];
@@ -654,11 +661,20 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     uint32_t pk[QG][2][8];
     const bool masked_tile = tflag[t] != 0;                    // workgroup-uniform
     const float csc = (MODE == ATTN_T5 ? 1.0f : p.scale) * kLog2e;
+    // wave-uniform: every (key - query) of this tile and wave at or beyond +far / -far
+    const bool far_pos = MODE == ATTN_T5 && far > 0 && k0 - qw1 >= far, far_neg = MODE == ATTN_T5 && far > 0 && k0 + 63 - qw0 <= -far;
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
       float x[2][16];
       float mt = -INFINITY;
       const float* bq = btab + (boff - qi[g] + k0 + 4 * hi);    // T5: bias of key (k0 + 4hi + j) is bq[j]
+      if (MODE == ATTN_T5 && (far_pos || far_neg)) {
+        const float cb = far_pos ? cfar_pos : cfar_neg;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[sub][r] = __builtin_fmaf(s[g][sub][r], csc, cb);
+      } else {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -674,6 +690,7 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
             x[sub][4 * gg + e] = v;
           }
         }
+      }
       }
       if (masked_tile) {
 #pragma unroll
@@ -1019,7 +1036,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_split_kernel(const 
 inline AttnDev to_dev(const AttnArgs& a) {
   AttnDev d;
   d.q = a.q; d.ldq = a.ldq; d.k = a.k; d.ldk = a.ldk; d.v = a.v; d.ldv = a.ldv; d.out = a.out; d.ldo = a.ldo;
-  d.kmask = a.kmask; d.relbias = a.relbias; d.B = a.B; d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk; d.scale = a.scale;
+  d.kmask = a.kmask; d.relbias = a.relbias; d.bias_far = (a.mode == ATTN_T5 && a.bias_far > 0 && a.bias_far < a.Lk && a.bias_far < a.Lq) ? a.bias_far : 0; d.B = a.B; d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk; d.scale = a.scale;
   d.mode = a.mode;
   d.Lkr = a.Lk_rows > 0 ? a.Lk_rows : a.Lk;
   d.q_off = a.q_off;

@@ -191,6 +191,8 @@ struct AttnArgs {
   void* out = nullptr; int ldo = 0;
   const uint8_t* kmask = nullptr;         // [B, Lk] 1 = attend; masked keys get score finfo(fp32).min
   const float* relbias = nullptr;         // T5: [H][2*Lk-1], index (j - i) + Lk - 1
+  int bias_far = 0;                       // T5: > 0 promises that relbias[h] is CONSTANT for j - i >= bias_far and for j - i <= -bias_far (the bucketed
+                                          // T5 table is, from |j - i| = 91 on): key tiles wholly beyond it take the constant instead of per-score reads
   int B = 0, H = 0, Lq = 0, Lk = 0, D = 0;
   float scale = 1.0f;
   int mode = ATTN_CROSS;

@@ -250,6 +250,8 @@ struct VimaHandle {
   float* t5_final = nullptr;
   std::vector<float> t5_relbias_host;            // [32][12]
   std::map<int, float*> t5_bias_tables;          // L -> device [12][2L-1]
+  std::map<int, int> t5_bias_far;                // L -> distance from which that table is constant on both sides (AttnArgs::bias_far; 0: never)
+  int op_bias_far = 0;                           // option "op_bias_far": AttnArgs::bias_far of vima_op_attention calls (tests)
   Lin t5_post; bool has_t5_post = false;
   float *pos_emb = nullptr, *xpos_emb = nullptr;
   struct DecLayer {
@@ -1061,6 +1063,18 @@ int t5_bias_table(VimaHandle* h, int L, float** out) {
     const int bkt = t5_bucket(d);
     for (int hh = 0; hh < kT5Heads; ++hh) t[(size_t)hh * W + d + L - 1] = h->t5_relbias_host[(size_t)bkt * kT5Heads + hh];
   }
+  {   // distance from which THIS table is constant on both sides for every head (the T5 bucket function saturates at |delta| = 91):
+      // AttnArgs::bias_far. Found by scanning the table itself, so it is exact whatever the bucket function.
+    int far = L;   // L: never
+    for (int n0 = L - 1; n0 >= 1; --n0) {
+      bool same = true;
+      for (int hh = 0; hh < kT5Heads && same; ++hh)
+        same = t[(size_t)hh * W + n0 + L - 1] == t[(size_t)hh * W + (L - 1) + L - 1] && t[(size_t)hh * W - n0 + L - 1] == t[(size_t)hh * W + 0];
+      if (!same) break;
+      far = n0;
+    }
+    h->t5_bias_far[L] = far < L ? far : 0;
+  }
   float* d = nullptr;
   HIPCK(hipMalloc((void**)&d, t.size() * 4));
   h->owned.push_back(d);
@@ -1082,7 +1096,7 @@ void t5_layer(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* ma
   a.k = R.offT(b.qkv, kT5Model); a.ldk = 3 * kT5Model;
   a.v = R.offT(b.qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
   a.out = b.ctx; a.ldo = kT5Model;
-  a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+  a.kmask = mask; a.relbias = table; a.bias_far = R.h->t5_bias_far.count(L) ? R.h->t5_bias_far[L] : 0; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
   a.mode = ATTN_T5;
   R.attn(a, attn_impl);
   R.linear(b.ctx, kT5Model, Ly.o, rows, ACT_NONE, nullptr, 0, x, kT5Model, x, kT5Model, nullptr, 0);
@@ -1123,7 +1137,7 @@ const float* t5_layer_fp8(Run& R, const VimaHandle::T5Layer& Ly, const uint8_t* 
   a.k = R.offT(b.qkv, kT5Model); a.ldk = 3 * kT5Model;
   a.v = R.offT(b.qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
   a.out = b.ctx; a.ldo = kT5Model;
-  a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+  a.kmask = mask; a.relbias = table; a.bias_far = R.h->t5_bias_far.count(L) ? R.h->t5_bias_far[L] : 0; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
   a.mode = ATTN_T5;
   R.attn(a, attn_impl);
   OTHER(R, launch_quant_fp8(b.ctx, kT5Model, rows, kT5Model, 1.0f / sc[1], b.ctx8, kT5Model, R.st), "quant_fp8");
@@ -1157,7 +1171,7 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
   a.k = R.offT(b.qkv, kT5Model); a.ldk = 3 * kT5Model;
   a.v = R.offT(b.qkv, 2 * kT5Model); a.ldv = 3 * kT5Model;
   a.out = b.ctx; a.ldo = kT5Model;
-  a.kmask = mask; a.relbias = table; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
+  a.kmask = mask; a.relbias = table; a.bias_far = R.h->t5_bias_far.count(L) ? R.h->t5_bias_far[L] : 0; a.B = B; a.H = kT5Heads; a.Lq = L; a.Lk = L; a.D = kT5D; a.scale = 1.0f;
   a.mode = ATTN_T5;
   R.attn(a, attn_impl);
   cal(1, b.ctx, kT5Model);
@@ -1552,6 +1566,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "dual_stream") h->dual_stream = (int)value;
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
   else if (k == "op_stream_T") h->op_stream_T = (int)value;
+  else if (k == "op_bias_far") h->op_bias_far = (int)value;
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
   else if (k == "fp8_headroom_pct") { h->fp8_headroom_pct = value < 100 ? 100 : (int)value; h->fp8_ready = false; h->vit8_ready = false; h->kv8_ready = false; }
@@ -2276,7 +2291,7 @@ int vima_op_attention(VimaHandle* h, const float* q, const float* k, const float
   OTHER(R, launch_cast(v, vT, nk, h->bf16, R.st), "cast");
   AttnArgs a;
   a.q = qT; a.ldq = H * D; a.k = kT; a.ldk = H * D; a.v = vT; a.ldv = H * D; a.out = oT; a.ldo = H * D;
-  a.kmask = kmask; a.relbias = relbias; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale; a.mode = mode;
+  a.kmask = kmask; a.relbias = relbias; a.bias_far = h->op_bias_far; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale; a.mode = mode;
   if (impl == 1 && !h->bf16) return fail("vima_op_attention: the MFMA kernel needs bf16 precision");
   if (R.attn(a, impl)) return R.err;
   if (h->bf16) {
