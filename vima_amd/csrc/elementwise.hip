@@ -337,6 +337,40 @@ __global__ __launch_bounds__(256) void prompt_assemble_kernel(const int* __restr
   if (lane == 0) mask[row] = m;
 }
 
+// The same gather writing what the T5 stack's fused-RMSNorm chain starts from -- the operand-type copy of the row and its sum of squares
+// (rms_stats_kernel's output, same lane -> element mapping and the same summation order: identical bits) -- instead of the fp32 row: with the
+// residual stream carried in the operand type the fp32 prompt is never read again, so its 403-MB write and read (batch 256) disappear.
+template <typename T>
+__global__ __launch_bounds__(256) void prompt_assemble_stats_kernel(const int* __restrict__ tok_src, const long long* __restrict__ word_ids,
+                                                                     const float* __restrict__ word_table, const float* __restrict__ obj_tokens,
+                                                                     const uint8_t* __restrict__ obj_mask, T* xT, float* ssq, uint8_t* mask,
+                                                                     int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int s = tok_src[row];
+  const float* src = nullptr;
+  uint8_t m = 0;
+  if (s >= 0) {
+    src = word_table + word_ids[s] * E;
+    m = 1;
+  } else if (s <= -2) {
+    const long long o = -(long long)s - 2;
+    src = obj_tokens + o * E;
+    m = obj_mask[o] ? 1 : 0;
+  }
+  const int nv = E >> 2;
+  float q = 0.f;
+  for (int c = lane; c < nv; c += 64) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src) v = *reinterpret_cast<const float4*>(src + c * 4);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    store4(xT + (long long)row * E + c * 4, v);
+  }
+  q = wave_sum(q);
+  if (lane == 0) { ssq[row] = q; mask[row] = m; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // decoder input (vima_policy.py:124-146 + xattn_gpt.py:101-106): per batch element b, sequence position l:
 //   step t = l / (Q+1), slot s = l % (Q+1); s < Q -> obs token (t,b,s) else action token (t,b); action mask = True
@@ -689,6 +723,19 @@ int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const 
   if (E % 4) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(prompt_assemble_kernel, dim3(nblk(rows, 4)), dim3(256), 0, st, tok_src, word_ids, word_table,
                      obj_tokens, obj_mask, x, mask, rows, E);
+  return (int)hipGetLastError();
+}
+
+int launch_prompt_assemble_stats(const int* tok_src, const long long* word_ids, const float* word_table, const float* obj_tokens,
+                                 const uint8_t* obj_mask, void* xT, float* ssq, uint8_t* mask, int rows, int E, bool is_bf16, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (E % 4) return (int)hipErrorInvalidValue;
+  if (is_bf16)
+    hipLaunchKernelGGL(prompt_assemble_stats_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, tok_src, word_ids, word_table, obj_tokens,
+                       obj_mask, (bf16_t*)xT, ssq, mask, rows, E);
+  else
+    hipLaunchKernelGGL(prompt_assemble_stats_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, tok_src, word_ids, word_table, obj_tokens,
+                       obj_mask, (float*)xT, ssq, mask, rows, E);
   return (int)hipGetLastError();
 }
 

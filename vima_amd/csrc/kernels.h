@@ -143,6 +143,10 @@ int launch_add_row_table(float* out, int rows, int E, const float* table, const 
 int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const float* word_table,
                            const float* obj_tokens, const uint8_t* obj_mask, float* x, uint8_t* mask, int rows,
                            int E, hipStream_t st);
+// the same gather as the entry of the T5 stack's fused-RMSNorm chain: operand-type rows xT [rows, E] + ssq[r] = sum xT-source[r][:]^2 (what
+// launch_rms_stats would produce from the fp32 rows, bit for bit) + mask; the fp32 prompt is not materialised
+int launch_prompt_assemble_stats(const int* tok_src, const long long* word_ids, const float* word_table, const float* obj_tokens,
+                                 const uint8_t* obj_mask, void* xT, float* ssq, uint8_t* mask, int rows, int E, bool is_bf16, hipStream_t st);
 // decoder input: interleave [o_1..o_Q, a] per step, cumsum position ids, + positions_embed
 int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table,
                      int n_pos, float* x32, void* xT, uint8_t* mask, int T, int B, int Q, int L_act, int E,

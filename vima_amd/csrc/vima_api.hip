@@ -1201,7 +1201,12 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
 
 // T5 encoder stack on x fp32 [B*L, 768] (updated in place); result (after final RMSNorm) -> out32 and/or outT.
 // Samples are independent, so with dual_stream the batch is split in two halves that run the 12 layers on two streams.
-int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, void* outT) {
+// `src` (vima_prompt_encode): the stack's input is still to be ASSEMBLED from word embeddings / object tokens (x == nullptr, `mask` is the
+// output mask the assembly writes). With the fused RMSNorm chain and the stream in the operand type the assembly writes that chain's entry
+// (operand-type rows + row sums of squares) directly and the fp32 prompt never exists; otherwise it is assembled into a workspace x first.
+struct PromptSrc { const int* tok_src; const long long* word_ids; const float* objtok; const uint8_t* objmask; };
+
+int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, void* outT, const PromptSrc* src = nullptr) {
   VimaHandle* h = R.h;
   float* table = nullptr;
   if (int e = t5_bias_table(h, L, &table)) return R.err = e;
@@ -1244,15 +1249,31 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
       buf[i].u8 = R.ws<uint8_t>(rows * kT5FF);
     }
   if (R.err) return R.err;
-  Run Rb{h, h->aux};
-  if (dual && fork_aux(R)) return R.err = 1;
-  const long long off1 = (long long)nb[0] * L;      // first row of the second half
   // with the opt-in split-K, small problems keep the standalone RMSNorm: the producer-side statistics are not available
   // from the two-pass split-K, and the norm kernels cost microseconds there
   const bool fused = h->t5_fuse_rms != 0 && (!gemm_splitk_enabled(&h->tune) || (long long)nb[0] * L >= 8192);
+  const bool direct = src != nullptr && fused && h->stream_T != 0;   // the assembly writes the chain's entry itself
+  if (src && !direct) {   // assemble the fp32 prompt first (before the halves diverge)
+    x = R.ws<float>((size_t)B * L * kT5Model);
+    if (R.err) return R.err;
+    OTHER(R, launch_prompt_assemble(src->tok_src, src->word_ids, h->word_table, src->objtok, src->objmask, x, const_cast<uint8_t*>(mask),
+                                    B * L, kT5Model, R.st), "prompt_assemble");
+  }
+  Run Rb{h, h->aux};
+  if (dual && fork_aux(R)) return R.err = 1;
+  const long long off1 = (long long)nb[0] * L;      // first row of the second half
   const float* ss[2] = {nullptr, nullptr};
   int parts = 1;
-  if (fused) {   // entry of the chain: operand-type copy of x and its row sums of squares (one partial per row)
+  if (direct) {
+    OTHER(R, launch_prompt_assemble_stats(src->tok_src, src->word_ids, h->word_table, src->objtok, src->objmask, buf[0].hT, buf[0].ssB,
+                                          const_cast<uint8_t*>(mask), nb[0] * L, kT5Model, h->bf16, R.st), "prompt_assemble");
+    ss[0] = buf[0].ssB;
+    if (dual) {
+      OTHER(Rb, launch_prompt_assemble_stats(src->tok_src + off1, src->word_ids, h->word_table, src->objtok, src->objmask, buf[1].hT, buf[1].ssB,
+                                             const_cast<uint8_t*>(mask) + off1, nb[1] * L, kT5Model, h->bf16, Rb.st), "prompt_assemble");
+      ss[1] = buf[1].ssB;
+    }
+  } else if (fused) {   // entry of the chain: operand-type copy of x and its row sums of squares (one partial per row)
     R.other(launch_rms_stats(x, nb[0] * L, kT5Model, buf[0].hT, buf[0].ssB, h->bf16, R.st), "rms_stats");
     ss[0] = buf[0].ssB;
     if (dual) {
@@ -1750,14 +1771,11 @@ int vima_prompt_encode(VimaHandle* h, const int64_t* word_ids, int n_words, cons
     concat_mask(R, mask, n_img, qv, objmask);
   }
   const int rows = B * Lp;
-  float* x = R.ws<float>((size_t)rows * 768);
-  if (R.err) return R.err;
-  OTHER(R, launch_prompt_assemble(tok_src, (const long long*)word_ids, h->word_table, objtok, objmask, x, out_mask, rows, 768, R.st),
-        "prompt_assemble");
-  if (!h->has_t5_post) return t5_stack(R, x, out_mask, B, Lp, out_tokens, nullptr);
+  const PromptSrc src{tok_src, (const long long*)word_ids, objtok, objmask};   // assembled inside the stack (see t5_stack)
+  if (!h->has_t5_post) return t5_stack(R, nullptr, out_mask, B, Lp, out_tokens, nullptr, &src);
   void* yT = R.wsT((size_t)rows * 768);
   if (R.err) return R.err;
-  if (t5_stack(R, x, out_mask, B, Lp, nullptr, yT)) return R.err;
+  if (t5_stack(R, nullptr, out_mask, B, Lp, nullptr, yT, &src)) return R.err;
   return R.linear(yT, 768, h->t5_post, rows, ACT_NONE, nullptr, 0, nullptr, 0, out_tokens, E, nullptr, 0);
 }
 
