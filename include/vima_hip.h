@@ -269,6 +269,8 @@ int vima_t5_bucket(int relative_position);
  *                            "vit_prune_last" [1] last ViT block evaluated for the cls row only (identical values)
  *                            "fp8_recalibrate" (any value) VIMA_PRECISION_FP8: the next pass of every group measures the activation scales again
  *                            "fp8_headroom_pct" [125] VIMA_PRECISION_FP8: scale = pct/100 x max |x| / 448 (>= 100); setting it re-calibrates
+ *                            "kv_headmajor" [1] decoder prompt K / V written head-major ([B][2 heads][Lp][head dim]) where the projection runs on the
+ *                                               persistent 256x256 GEMM (batch x prompt large enough): same values, contiguous reads in the cross attention
  *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass

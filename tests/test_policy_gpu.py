@@ -689,3 +689,57 @@ def test_per_sample_episode_restart_in_incremental_decoding(prec):
         ref = fresh[k][0]
         assert max_abs(mixed[2 + k][1], ref) <= tol * max(1.0, ref.abs().max().item()), (k, max_abs(mixed[2 + k][1], ref))
     assert max_abs(mixed[3][1], plain[3][1]) > 10 * tol            # the restart really changed sample 1's trajectory
+
+
+def test_head_major_prompt_kv_cache_is_bit_identical():
+    """Round 4: where the decoder's prompt K / V projection runs on the persistent 256x256 GEMM (batch x prompt large enough) its epilogue
+    writes the per-layer K / V head-major ([B][2 heads][Lp][head dim], option kv_headmajor, default on) and every attention kernel reads it
+    through batch / head strides. Same values, same arithmetic: full-history forward (cache built, then re-used), incremental steps, a
+    per-sample restart (whose rows are rebuilt row-major and transposed) and the stateless path must all equal the row-major layout
+    bit for bit. 2M model (E 256, 8 heads of 32), 40 samples x 512-token prompt = 160 tiles of 256x256 in the projection."""
+    cfg = syn.config("2M", xattn_n_positions=512)
+    sd = syn.make_state_dict(cfg, 11, head_gain=0.5)
+    B, Lp, Q, E = 40, 512, 4, cfg.embed_dim
+    g = torch.Generator().manual_seed(3)
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = (torch.rand(B, Lp, generator=g) > 0.1)
+    pmask[:, 0] = True
+    pmask = pmask.to(DEV)
+    ptok2 = torch.randn(Lp, B, E, generator=g).to(DEV)
+    otok = [torch.randn(T, B, Q, E, generator=g).to(DEV) for T in (1, 2, 9)]            # T = 9: 44 queries (the 1-wave MFMA kernel); 1, 2: split-key
+    omask = [torch.ones(T, B, Q, dtype=torch.bool, device=DEV) for T in (1, 2, 9)]
+    atok = [None] + [torch.randn(T - 1, B, E, generator=g).to(DEV) for T in (2, 9)]
+    step_o = [torch.randn(1, B, Q, E, generator=g).to(DEV) for _ in range(4)]
+    step_a = [torch.randn(1, B, E, generator=g).to(DEV) for _ in range(4)]
+
+    def run(hm, cache):
+        pol = loaded_policy(cfg, sd, "bf16", kv_headmajor=hm)
+        pol.cache_prompt_kv = cache
+        outs = []
+        pol.prof_enable(True)
+        outs.append(pol.forward(otok[0], omask[0], atok[0], ptok, pmask).clone())             # builds the cache (or stateless)
+        torch.cuda.synchronize()
+        kinds = pol.prof_read_gemm_kernels()
+        pol.prof_enable(False)
+        outs.append(pol.forward(otok[1], omask[1], atok[1], ptok, pmask).clone())             # re-uses it
+        outs.append(pol.forward(otok[2], omask[2], atok[2], ptok, pmask).clone())
+        pt, pm = ptok, pmask
+        for k in range(4):                                                                    # incremental episode with a restart before step 2
+            if k == 2:
+                flags = torch.zeros(B, dtype=torch.bool)
+                flags[[1, 17]] = True
+                pt = ptok.clone()
+                pt[:, 1], pt[:, 17] = ptok2[:, 1], ptok2[:, 17]
+                pol.restart_samples(flags, pt, pm)
+            outs.append(pol.forward_step(step_o[k], torch.ones(1, B, Q, dtype=torch.bool, device=DEV), step_a[k - 1] if k > 0 else None, pt, pm, step=k).clone())
+        return outs, kinds
+
+    ref, kinds0 = run(0, True)
+    got, kinds1 = run(1, True)
+    assert any("gemm_pp_kernel" in k or "gemm_persistent_kernel" in k for k in kinds1), kinds1.keys()   # the projection took the kernel that writes head-major
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+    stateless, _ = run(1, False)
+    for i in range(3):
+        assert torch.equal(stateless[i], ref[i]), i

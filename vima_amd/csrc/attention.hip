@@ -202,6 +202,7 @@ struct AttnDev {
   float scale;
   int mode;
   int Lkr;      // K / V / mask rows per sample in memory (>= Lk)
+  long long k_bs, v_bs; int k_hs, v_hs;   // K / V batch and head strides in elements (AttnArgs; defaults Lkr * ld and D)
   int q_off;    // causal: query i sits at global position i + q_off
   long long* dbg;   // optional (4-wave kernel): per workgroup 8 accumulated shader-clock phase totals of wave 0
 };
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
   const float* rb = p.relbias ? p.relbias + (long long)h * (2 * p.Lk - 1) : nullptr;
   float mx = -INFINITY;
   for (int j = lane; j < p.Lk; j += 64) {
-    const T* kp = reinterpret_cast<const T*>(p.k) + ((long long)b * p.Lkr + j) * p.ldk + h * D;
+    const T* kp = reinterpret_cast<const T*>(p.k) + b * p.k_bs + (long long)j * p.ldk + h * p.k_hs;
     float d = 0.f;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnDev p) {
   __syncthreads();
   for (int dl = lane; dl < D; dl += 64) {   // D = 128: two output columns per lane
     float acc = 0.f;
-    const T* vp = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lkr * p.ldv + h * D + dl;
+    const T* vp = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs + dl;
     for (int j = 0; j < p.Lk; ++j) acc = fmaf(sc[j], Elem<T>::load(vp + (long long)j * p.ldv), acc);
     T* op = reinterpret_cast<T*>(p.out) + ((long long)b * p.Lq + i) * p.ldo + h * D + dl;
     Elem<T>::store(op, acc / l);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     {
       const int krow = (k0 + l31) < p.Lk ? (k0 + l31) : p.Lk - 1;
-      const bf16_t* kp = K + ((long long)b * p.Lkr + krow) * p.ldk + h * D + hi * 8;
+      const bf16_t* kp = K + b * p.k_bs + (long long)krow * p.ldk + h * p.k_hs + hi * 8;
 #pragma unroll
       for (int dd = 0; dd < KD; ++dd) {
         const uint4 u = *reinterpret_cast<const uint4*>(kp + dd * 16);
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttnDev p) {
       const int c = lane + c0 * 64;
       const int key = c / (D / 8), dc = c % (D / 8);
       const int vrow = (k0 + key) < p.Lk ? (k0 + key) : p.Lk - 1;
-      const uint4 u = *reinterpret_cast<const uint4*>(V + ((long long)b * p.Lkr + vrow) * p.ldv + h * D + dc * 8);
+      const uint4 u = *reinterpret_cast<const uint4*>(V + b * p.v_bs + (long long)vrow * p.ldv + h * p.v_hs + dc * 8);
       const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -558,8 +559,8 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   // V: instruction j fills half (j & 1) of sub-tile j / 2 ([64 keys][16 d], 32-byte rows): lane -> key 32 (j & 1) + lane / 2,
   // 16-byte part lane & 1 of the row's 32-byte segment 2 (j / 2) + part. Per-lane byte offsets inside a tile are fixed; the tile's
   // first row is a wave-uniform pointer (SGPRs), so a tile costs no vector address arithmetic.
-  const bf16_t* Kb = K + (long long)b * p.Lkr * p.ldk + h * D;
-  const bf16_t* Vb = V + (long long)b * p.Lkr * p.ldv + h * D;
+  const bf16_t* Kb = K + b * p.k_bs + h * p.k_hs;
+  const bf16_t* Vb = V + b * p.v_bs + h * p.v_hs;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem4;
   auto k_key = [&](int i) { return ((w * NI + i) * 64 + lane) / CPR; };
   auto k_chunk = [&](int i) { const int pp = ((w * NI + i) * 64 + lane) % CPR; return kswz<D>(k_key(i), pp); };
@@ -851,27 +852,29 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_split_kernel(const 
   static_assert(CH == 2 || CH == 4, "staging registers");
   uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
   uint4 kregb0, kregb1, kregb2, kregb3, vregb0, vregb1, vregb2, vregb3;
+  const bf16_t* Kbh = K + b * p.k_bs + h * p.k_hs;     // this (batch, head)'s first key / value row
+  const bf16_t* Vbh = V + b * p.v_bs + h * p.v_hs;
   auto gaddr = [&](int t, int i, const bf16_t* base, int ld) {
     const int id = tid + i * 256;
     const int key = id / CPR, c = id % CPR;
     int row = t * SPLIT_TK + key;
     row = row < p.Lk ? row : p.Lk - 1;
-    return reinterpret_cast<const uint4*>(base + ((long long)b * p.Lkr + row) * ld + h * D + c * 8);
+    return reinterpret_cast<const uint4*>(base + (long long)row * ld + c * 8);
   };
   auto gload = [&](int t, auto set) {
     if constexpr (decltype(set)::value == 0) {
-      kreg0 = *gaddr(t, 0, K, p.ldk); vreg0 = *gaddr(t, 0, V, p.ldv);
-      kreg1 = *gaddr(t, 1, K, p.ldk); vreg1 = *gaddr(t, 1, V, p.ldv);
+      kreg0 = *gaddr(t, 0, Kbh, p.ldk); vreg0 = *gaddr(t, 0, Vbh, p.ldv);
+      kreg1 = *gaddr(t, 1, Kbh, p.ldk); vreg1 = *gaddr(t, 1, Vbh, p.ldv);
       if constexpr (CH > 2) {
-        kreg2 = *gaddr(t, 2, K, p.ldk); vreg2 = *gaddr(t, 2, V, p.ldv);
-        kreg3 = *gaddr(t, 3, K, p.ldk); vreg3 = *gaddr(t, 3, V, p.ldv);
+        kreg2 = *gaddr(t, 2, Kbh, p.ldk); vreg2 = *gaddr(t, 2, Vbh, p.ldv);
+        kreg3 = *gaddr(t, 3, Kbh, p.ldk); vreg3 = *gaddr(t, 3, Vbh, p.ldv);
       }
     } else {
-      kregb0 = *gaddr(t, 0, K, p.ldk); vregb0 = *gaddr(t, 0, V, p.ldv);
-      kregb1 = *gaddr(t, 1, K, p.ldk); vregb1 = *gaddr(t, 1, V, p.ldv);
+      kregb0 = *gaddr(t, 0, Kbh, p.ldk); vregb0 = *gaddr(t, 0, Vbh, p.ldv);
+      kregb1 = *gaddr(t, 1, Kbh, p.ldk); vregb1 = *gaddr(t, 1, Vbh, p.ldv);
       if constexpr (CH > 2) {
-        kregb2 = *gaddr(t, 2, K, p.ldk); vregb2 = *gaddr(t, 2, V, p.ldv);
-        kregb3 = *gaddr(t, 3, K, p.ldk); vregb3 = *gaddr(t, 3, V, p.ldv);
+        kregb2 = *gaddr(t, 2, Kbh, p.ldk); vregb2 = *gaddr(t, 2, Vbh, p.ldv);
+        kregb3 = *gaddr(t, 3, Kbh, p.ldk); vregb3 = *gaddr(t, 3, Vbh, p.ldv);
       }
     }
   };
@@ -1039,6 +1042,8 @@ inline AttnDev to_dev(const AttnArgs& a) {
   d.kmask = a.kmask; d.relbias = a.relbias; d.bias_far = (a.mode == ATTN_T5 && a.bias_far > 0 && a.bias_far < a.Lk && a.bias_far < a.Lq) ? a.bias_far : 0; d.B = a.B; d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk; d.scale = a.scale;
   d.mode = a.mode;
   d.Lkr = a.Lk_rows > 0 ? a.Lk_rows : a.Lk;
+  d.k_bs = a.k_bs > 0 ? a.k_bs : (long long)d.Lkr * a.ldk; d.v_bs = a.v_bs > 0 ? a.v_bs : (long long)d.Lkr * a.ldv;
+  d.k_hs = a.k_hs > 0 ? a.k_hs : a.D; d.v_hs = a.v_hs > 0 ? a.v_hs : a.D;
   d.q_off = a.q_off;
   d.dbg = a.tune ? a.tune->attn_dbg : nullptr;
   return d;

@@ -726,6 +726,28 @@ int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const 
   return (int)hipGetLastError();
 }
 
+// rows [L][N] (row-major) -> [N / D][L][D]: one sample's K | V rows into the head-major prompt cache (vima_decode_restart); 16-byte chunks
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_headmajor_kernel(const T* __restrict__ in, T* __restrict__ out, int L, int N, int D) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int cpr = N / EPC;
+  if (i >= (long long)L * cpr) return;
+  const int l = (int)(i / cpr), n = (int)(i % cpr) * EPC;
+  const uint4 v = *reinterpret_cast<const uint4*>(in + (long long)l * N + n);
+  *reinterpret_cast<uint4*>(out + ((long long)(n / D) * L + l) * D + n % D) = v;
+}
+
+int launch_rows_to_headmajor(const void* in, void* out, int L, int N, int D, bool is_bf16, hipStream_t st) {
+  const int epc = is_bf16 ? 8 : 4;
+  if (L <= 0 || N <= 0) return 0;
+  if (D % epc || N % D) return (int)hipErrorInvalidValue;
+  const long long n = (long long)L * (N / epc);
+  if (is_bf16) hipLaunchKernelGGL(rows_to_headmajor_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, L, N, D);
+  else hipLaunchKernelGGL(rows_to_headmajor_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, st, (const float*)in, (float*)out, L, N, D);
+  return (int)hipGetLastError();
+}
+
 int launch_prompt_assemble_stats(const int* tok_src, const long long* word_ids, const float* word_table, const float* obj_tokens,
                                  const uint8_t* obj_mask, void* xT, float* ssq, uint8_t* mask, int rows, int E, bool is_bf16, hipStream_t st) {
   if (rows <= 0) return 0;

@@ -241,6 +241,7 @@ struct GemmDev {
   float* out32; int ld32;
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
+  int hm_D, hm_L;   // head-major output of the 256x256 bf16-output epilogue (GemmArgs::hm_D / hm_L; 0 = row-major)
   float* ssq_out; const float* rs_ssq; int rs_parts; float rs_invk, rs_eps;
   const float* wscale;   // fp8 weights: per-output-channel dequantisation scale [N], applied to the accumulator column
   float ascale;          // fp8 ACTIVATIONS (gemm_pp_kernel<.., F8>): the A operand's per-tensor dequantisation scale (x wscale[n])
@@ -849,6 +850,12 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
             const T* q_ = outT + m * p.ldT + n; const u32x4_t ov = {o.x, o.y, o.z, o.w};
             asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(q_), "v"(ov) : "memory"); }
 #else
+          if (EPI == 1 && p.hm_D) {   // head-major: [batch][head][row][hm_D]; a tile's 256 rows lie in one batch (hm_L % 256 == 0), the lane's 8 columns in one head
+            const int lg = 31 - __builtin_clz((unsigned)p.hm_D);
+            const long long bq = m0 / p.hm_L;
+            const long long o_ = bq * (long long)p.hm_L * (p.N - p.hm_D) + m * p.hm_D + ((long long)(n >> lg) * p.hm_L << lg) + (n & (p.hm_D - 1));
+            *reinterpret_cast<uint4*>(outT + o_) = o;
+          } else
           if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
 #endif
           }
@@ -2118,6 +2125,10 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.resT && (a.res || a.batch > 1 || a.act != ACT_NONE)) return (int)hipErrorInvalidValue;
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
+  d.hm_D = a.hm_D; d.hm_L = a.hm_L;
+  if (a.hm_D && (sizeof(T) != 2 || !a.outT || a.out32 || a.mul || a.res || a.resT || a.out8 || a.ssq_out || a.rb > 0 || a.batch > 1 || a.grp_col || a.W2 ||
+                 !gemm_headmajor_ok(a.tune, a.M, a.N, a.K, a.lda, a.ldw, a.hm_D, a.hm_L, a.a8)))
+    return (int)hipErrorInvalidValue;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
   d.wscale = a.w8 ? a.wscale : nullptr;
   d.ascale = a.a8 ? a.ascale : 1.0f;
@@ -2176,10 +2187,10 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       const int e = launch_persistent(d, a, st);
       if (e >= 0) { if (a.kernel_id) *a.kernel_id = 2000 + (a.act + 1) * 10 + epi_id; return e; }
     }
-    if (a.a8) return (int)hipErrorInvalidValue;
+    if (a.a8 || a.hm_D) return (int)hipErrorInvalidValue;   // (head-major output exists in the persistent kernels' epilogue only)
     if (large) { if (a.kernel_id) *a.kernel_id = 4000 + (a.act + 1) * 10; return launch_tile<T, TileL, true>(d, a, v, st); }
   }
-  if (a.a8) return (int)hipErrorInvalidValue;
+  if (a.a8 || a.hm_D) return (int)hipErrorInvalidValue;
 #ifdef VIMA_GEMM_LAB
   return (int)hipErrorInvalidValue;
 #else
@@ -2230,6 +2241,20 @@ int gemm_dual_ok(const Tuning* t, int M, int N) {
   if (!gemm_grouped_ok(t) || M <= 0 || N <= 0 || N % 4 != 0) return 0;
   if (M <= 32) return 1;
   return (long long)((M + 63) / 64) * ((N + 63) / 64) <= gemm_res_maxwg(t) ? 1 : 0;
+}
+// Head-major output (GemmArgs::hm_D / hm_L) exists in the persistent 256x256 kernels' bf16-output epilogue: the problem must take that path
+// (same conditions as launch_t's: the large-tile rule, full tiles, the persistent / raster / epilogue knobs, 32-bit LDS-DMA offsets; fp8 operands: gemm_a8_ok),
+// a batch of hm_L rows must be whole tiles and a head a power of two >= 8 columns.
+int gemm_headmajor_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw, int hm_D, int hm_L, int a8) {
+  if (hm_D < 8 || (hm_D & (hm_D - 1)) || hm_L <= 0 || hm_L % TileL::BM != 0 || M % hm_L != 0 || N % hm_D != 0) return 0;
+  if (gemm_wide(t)) return 0;   // the opt-in 256x384 kernel has its own epilogue
+  if (a8) return gemm_a8_ok(t, M, N, K, lda, ldw);
+  if (M <= 0 || N <= 0 || K < 128 || K % 64 != 0 || M % TileL::BM != 0 || N % TileL::BN != 0 || N % 8 != 0 || lda % 8 != 0 || ldw % 8 != 0) return 0;
+  const int gt = gemm_tile(t);
+  if (!(gt == 0 || gt == 2) || !gemm_persist(t) || gemm_raster(t) != 0 || !gemm_epi(t)) return 0;
+  if (gt == 0 && (M / TileL::BM) * (N / TileL::BN) < 160) return 0;
+  if (M * lda * 2 >= (1LL << 32) || N * ldw * 2 >= (1LL << 32)) return 0;
+  return 1;
 }
 // fp8 ACTIVATIONS (GemmArgs::a8) exist on gemm_pp_kernel<.., F8> only: mirrors, condition for condition, the path launch_t takes
 // for an a8 problem (anything else makes launch_gemm return hipErrorInvalidValue), so that callers can decide BEFORE quantising.

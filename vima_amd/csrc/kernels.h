@@ -59,6 +59,11 @@ struct GemmArgs {
   int ld32 = 0;
   void* outT = nullptr;
   int ldT = 0;
+  // HEAD-MAJOR output (hm_D > 0; bf16-only output of the persistent 256x256 kernels, ask gemm_headmajor_ok() first): rows are hm_L-row
+  // batches, columns hm_D-wide heads, and element (r, n) goes to outT[((r / hm_L) * (N / hm_D) + n / hm_D) * hm_L * hm_D + (r % hm_L) * hm_D + n % hm_D]
+  // -- [batch][head][row][hm_D], every head's rows contiguous -- instead of outT[r * ldT + n]. The decoder's prompt K / V cache is written
+  // this way so that the split-key cross attention streams 32-KB runs per (batch, head) instead of 64-byte slices of 3-KB rows.
+  int hm_D = 0, hm_L = 0;
   // output-row remap (outputs only): orow = (r / rb) * s_hi + (r % rb) * s_lo + ro ; rb == 0 -> identity
   int rb = 0, s_hi = 0, s_lo = 0, ro = 0;
   // RMS statistics fused into the GEMMs either side of a T5 RMSNorm (the norm's weight is folded into W at pack time):
@@ -104,6 +109,7 @@ size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
 int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
 int gemm_dual_ok(const Tuning* t, int M, int N);   // the DUAL form (GemmArgs::W2) is available for an [M, N] output with this handle's knobs
+int gemm_headmajor_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw, int hm_D, int hm_L, int a8);   // GemmArgs::hm_D / hm_L usable for this problem
 int gemm_a8_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw);   // an fp8-ACTIVATION GEMM (GemmArgs::a8) of this shape is launchable with this handle's knobs
 int gemm_grouped_ok(const Tuning* t);   // the grouped form (GemmArgs::grp_col) is available with this handle's knobs
 
@@ -147,6 +153,8 @@ int launch_prompt_assemble(const int* tok_src, const long long* word_ids, const 
 // launch_rms_stats would produce from the fp32 rows, bit for bit) + mask; the fp32 prompt is not materialised
 int launch_prompt_assemble_stats(const int* tok_src, const long long* word_ids, const float* word_table, const float* obj_tokens,
                                  const uint8_t* obj_mask, void* xT, float* ssq, uint8_t* mask, int rows, int E, bool is_bf16, hipStream_t st);
+// rows [L][N] of the operand type -> [N / D][L][D] (one sample's block of the head-major prompt K / V cache)
+int launch_rows_to_headmajor(const void* in, void* out, int L, int N, int D, bool is_bf16, hipStream_t st);
 // decoder input: interleave [o_1..o_Q, a] per step, cumsum position ids, + positions_embed
 int launch_dec_embed(const float* obs_tok, const uint8_t* obs_mask, const float* act_tok, const float* pos_table,
                      int n_pos, float* x32, void* xT, uint8_t* mask, int T, int B, int Q, int L_act, int E,
@@ -198,6 +206,11 @@ struct AttnArgs {
   int bias_far = 0;                       // T5: > 0 promises that relbias[h] is CONSTANT for j - i >= bias_far and for j - i <= -bias_far (the bucketed
                                           // T5 table is, from |j - i| = 91 on): key tiles wholly beyond it take the constant instead of per-score reads
   int B = 0, H = 0, Lq = 0, Lk = 0, D = 0;
+  // K / V addressing: element (b, h, j, d) of K sits at k + b * k_bs + h * k_hs + j * ldk + d (V likewise). 0 = the default layout, rows
+  // (b * Lk_rows + j) of width ldk with the heads side by side: k_bs = Lk_rows * ldk, k_hs = D. A head-major cache ([B][heads][Lk][D]: ldk = D,
+  // k_hs = Lk * D, k_bs = heads * Lk * D) is read with every (batch, head)'s keys contiguous.
+  long long k_bs = 0, v_bs = 0;
+  int k_hs = 0, v_hs = 0;
   float scale = 1.0f;
   int mode = ATTN_CROSS;
   // incremental decoding (keys / values / key mask live in an episode cache with room for Lk_rows >= Lk rows per sample,

@@ -252,6 +252,8 @@ struct VimaHandle {
   std::map<int, float*> t5_bias_tables;          // L -> device [12][2L-1]
   std::map<int, int> t5_bias_far;                // L -> distance from which that table is constant on both sides (AttnArgs::bias_far; 0: never)
   int op_bias_far = 0;                           // option "op_bias_far": AttnArgs::bias_far of vima_op_attention calls (tests)
+  int kv_headmajor = 1;                          // option "kv_headmajor": write the decoder's prompt K / V head-major where the projection GEMM allows it
+  bool kv_hm = false;                            // layout of the prompt K / V CACHE as built (kv_cache_mode 1): [B][2 Hx][Lp][D] instead of [B * Lp][2E]
   Lin t5_post; bool has_t5_post = false;
   float *pos_emb = nullptr, *xpos_emb = nullptr;
   struct DecLayer {
@@ -1588,6 +1590,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
   else if (k == "op_stream_T") h->op_stream_T = (int)value;
   else if (k == "op_bias_far") h->op_bias_far = (int)value;
+  else if (k == "kv_headmajor") { h->kv_headmajor = (int)value; h->kv_valid = false; }   // the next decode rebuilds the cache in the chosen layout
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
   else if (k == "fp8_headroom_pct") { h->fp8_headroom_pct = value < 100 ? 100 : (int)value; h->fp8_ready = false; h->vit8_ready = false; h->kv8_ready = false; }
@@ -1933,11 +1936,24 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
       OTHER(R, launch_quant_fp8(pT, E, rp, E, 1.0f / kv_scale, p8, E, R.st), "quant_fp8");
     }
   }
+  // Layout of the per-layer prompt K / V: head-major [B][2 Hx][Lp][Dx] when the projection runs on the persistent 256x256 kernels (whose epilogue
+  // can write it: GemmArgs::hm_D) -- the split-key cross attention then streams Lp x Dx contiguous elements per (batch, head) instead of 2 Dx-byte
+  // slices of 4 E-byte rows (round 3 measured 86 against 104 us per layer at the benchmark shape); row-major [B * Lp][2E] otherwise. A cache keeps
+  // the layout it was built with (h->kv_hm); the values are the same, so is every result.
+  const int Dx = E / Hx;
+  bool hm = false;
+  if (build_kv)
+    hm = h->kv_headmajor && h->bf16 && gemm_headmajor_ok(&h->tune, rp, 2 * E, E, E, E, Dx, Lp, p8 != nullptr ? 1 : 0) != 0;
+  else
+    hm = h->kv_hm;
+  if (use_cache && build_kv) h->kv_hm = hm;
   auto kv_proj = [&](Run& Rr, int i, void* KV) {
-    if (!p8) return Rr.linear(pT, E, h->dec[i].kv, rp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
     GemmArgs g;
-    g.A = p8; g.lda = E; g.a8 = 1; g.ascale = kv_scale; Rr.setW(g, h->dec[i].kv); g.M = rp; g.N = 2 * E; g.K = E; g.bias = h->dec[i].kv.b;
+    if (p8) { g.A = p8; g.lda = E; g.a8 = 1; g.ascale = kv_scale; }
+    else { g.A = pT; g.lda = E; }
+    Rr.setW(g, h->dec[i].kv); g.M = rp; g.N = 2 * E; g.K = E; g.bias = h->dec[i].kv.b;
     g.outT = KV; g.ldT = 2 * E;
+    if (hm) { g.hm_D = Dx; g.hm_L = Lp; }
     return Rr.gemm(g);
   };
   if (dual) {
@@ -1964,7 +1980,12 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     else if (build_kv)   // single stream: project right before use (without a cache all layers share one buffer)
       kv_proj(R, i, KV);
     AttnArgs a;
-    a.q = Qb; a.ldq = E; a.k = KV; a.ldk = 2 * E; a.v = R.offT(KV, E); a.ldv = 2 * E; a.out = ctx; a.ldo = E;
+    a.q = Qb; a.ldq = E; a.out = ctx; a.ldo = E;
+    if (hm) {   // [B][2 Hx][Lp][Dx]: K heads 0 .. Hx-1, V heads Hx .. 2 Hx-1
+      a.k = KV; a.v = R.offT(KV, (long long)E * Lp); a.ldk = a.ldv = Dx; a.k_hs = a.v_hs = Lp * Dx; a.k_bs = a.v_bs = (long long)2 * E * Lp;
+    } else {
+      a.k = KV; a.ldk = 2 * E; a.v = R.offT(KV, E); a.ldv = 2 * E;
+    }
     a.kmask = prompt_mask; a.B = B; a.H = Hx; a.Lq = Lq; a.Lk = Lp; a.D = E / Hx;
     a.scale = 1.0f / sqrtf((float)(E / Hx)); a.mode = ATTN_CROSS;
     R.attn(a, h->attn_impl);
@@ -2057,6 +2078,7 @@ int vima_decode_restart(VimaHandle* h, const uint8_t* restart, int B, const floa
   Run R{h, (hipStream_t)stream};
   uint8_t* flags = R.ws<uint8_t>((size_t)B);
   void* pT = R.wsT((size_t)Lp * E);
+  void* kvrow = h->kv_hm ? R.wsT((size_t)Lp * 2 * E) : nullptr;   // row-major K | V of one sample before the head-major transposition
   if (R.err) return R.err;
   HIPCK(hipMemcpyAsync(flags, restart, (size_t)B, hipMemcpyHostToDevice, R.st));
   OTHER(R, launch_restart_samples(flags, h->ep_mask, h->ep_poscnt, h->ep_fresh, B, h->ep_Lmax, R.st), "restart_samples");
@@ -2067,7 +2089,12 @@ int vima_decode_restart(VimaHandle* h, const uint8_t* restart, int B, const floa
                                h->cfg.xattn_n_positions, pT, 1, Lp, E, h->bf16, R.st), "prompt_pos");
     for (int i = 0; i < NL; ++i) {
       void* KV = reinterpret_cast<char*>(h->kv_cache) + kv_layer_bytes * i + (size_t)b * Lp * 2 * E * h->esz();
-      R.linear(pT, E, h->dec[i].kv, Lp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+      if (!h->kv_hm) {
+        R.linear(pT, E, h->dec[i].kv, Lp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, KV, 2 * E);
+      } else {   // head-major cache: the sample's block is [2 Hx][Lp][Dx]; Lp rows are too few for the kernel that writes it directly
+        R.linear(pT, E, h->dec[i].kv, Lp, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, kvrow, 2 * E);
+        OTHER(R, launch_rows_to_headmajor(kvrow, KV, Lp, 2 * E, E / h->cfg.xattn_n_heads, h->bf16, R.st), "rows_to_headmajor");
+      }
     }
   }
   return R.err;
