@@ -649,7 +649,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // HAS_BIAS / HAS_RS (fused-RMSNorm row scale) are compile-time here: as runtime flags hipcc turned the conditional adds into
 // v_pk_add + one v_cndmask per value and kept the x rsc multiply -- 256 of the 321 VALU instructions per wave of a
 // bias-less, scale-less epilogue (every T5 GEMM) did nothing, and the epilogue is VALU-issue-bound (2 waves per SIMD).
-template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS>
+template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS, bool OUT8>
 __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
                                                        int lane, int m0, int n0, int wm, int wn) {
   using T = bf16_t;
@@ -660,7 +660,10 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   // slab row r keeps its eight 16-B chunks at slot c ^ fsw(r), fsw = r&7 with its two low bits swapped
   auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
   float* stg = reinterpret_cast<float*>(slab);
-  constexpr bool WIDE8 = EPI == 1 || EPI == 2 || EPI == 4;      // bf16-only output, 16-byte stores
+  constexpr bool WIDE8 = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5;      // bf16-only output, 16-byte stores
+  // the fp8 copy of the output (GemmDev::out8) as a compile-time capability: only the fp8-operand kernels' consumers ask for it, and as run-time
+  // branches per store (pointer tests that also fence the scheduler) it cost the bf16 launches 1.3-1.6 % (profiles/r04_gemm_epilogue_branches.txt)
+  constexpr bool O8 = OUT8 && (EPI == 1 || EPI == 4 || EPI == 5);
   const T* mul = EPI == 2 ? reinterpret_cast<const T*>(p.mul) : nullptr;
   const float* res = EPI == 3 ? p.res : nullptr;
   float* out32 = EPI == 3 ? p.out32 : nullptr;
@@ -749,9 +752,9 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
 #ifdef VIMA_LAB_NOSTORE   // timing-only ablation: the output tile is never written
         asm volatile("" ::"v"(h_o[it].x), "v"(h_o[it].y), "v"(h_o[it].z), "v"(h_o[it].w));
 #else
-        if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = h_o[it];
+        if (!O8 || outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = h_o[it];
 #endif
-        if (EPI == 4 && p.out8) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = h_o8[it];
+        if (EPI == 4 && O8 && p.out8) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = h_o8[it];
         if (EPI == 4 && ssq_out && (elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = h_sq[it];
       } else {
         store4(out32 + m * p.ld32 + n, h_v[it]);
@@ -850,16 +853,16 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
             const T* q_ = outT + m * p.ldT + n; const u32x4_t ov = {o.x, o.y, o.z, o.w};
             asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(q_), "v"(ov) : "memory"); }
 #else
-          if (EPI == 1 && p.hm_D) {   // head-major: [batch][head][row][hm_D]; a tile's 256 rows lie in one batch (hm_L % 256 == 0), the lane's 8 columns in one head
+          if constexpr (EPI == 5) {   // head-major: [batch][head][row][hm_D]; a tile's 256 rows lie in one batch (hm_L % 256 == 0), the lane's 8 columns in one head
             const int lg = 31 - __builtin_clz((unsigned)p.hm_D);
             const long long bq = m0 / p.hm_L;
             const long long o_ = bq * (long long)p.hm_L * (p.N - p.hm_D) + m * p.hm_D + ((long long)(n >> lg) * p.hm_L << lg) + (n & (p.hm_D - 1));
             *reinterpret_cast<uint4*>(outT + o_) = o;
           } else
-          if (outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+          if (!O8 || outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
 #endif
           }
-          if ((EPI == 1 || EPI == 4) && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
+          if (O8 && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
             const float q = p.out8_inv;
             auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); };
             int w0 = 0, w1 = 0;
@@ -889,22 +892,22 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   if (AUX) emit_stores(MI * NI - 1);
 }
 
-template <int ACT, int EPI, bool W8>
+template <int ACT, int EPI, bool W8, bool OUT8 = true>
 __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
                                                   int lane, int m0, int n0, int wm, int wn) {
   const bool hb = p.bias != nullptr;                                   // kernel arguments: wave-uniform branches
-  const bool hr = (EPI == 0 || EPI == 1) && p.rs_ssq != nullptr;
-  if constexpr (EPI == 0 || EPI == 1) {
+  const bool hr = (EPI == 0 || EPI == 1 || EPI == 5) && p.rs_ssq != nullptr;
+  if constexpr (EPI == 0 || EPI == 1 || EPI == 5) {
     if (hb) {
-      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-      else tile_epilogue_256_impl<ACT, EPI, W8, true, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     } else {
-      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-      else tile_epilogue_256_impl<ACT, EPI, W8, false, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     }
   } else {
-    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-    else tile_epilogue_256_impl<ACT, EPI, W8, false, false>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
   }
 }
 
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_persistent_kernel(cons
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       rscv[mi] = 1.0f;
-      if ((EPI == 0 || EPI == 1) && p.rs_ssq) {
+      if ((EPI == 0 || EPI == 1 || EPI == 5) && p.rs_ssq) {
         int mr = m0 + wm * (MI * 32) + mi * 32 + tl31; mr = mr < p.M ? mr : p.M - 1;
         rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
       }
@@ -1292,7 +1295,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       rscv[mi] = 1.0f;
-      if (EPI == 1 && p.rs_ssq) {
+      if ((EPI == 1 || EPI == 5) && p.rs_ssq) {
         const int mr = m0 + wm * (MI * 32) + mi * 32 + tl31;
         rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
       }
@@ -1398,7 +1401,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     if (wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stamp(2);
-    tile_epilogue_256<ACT, EPI, F8>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
+    tile_epilogue_256<ACT, EPI, F8, F8>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);   // fp8 copy of the output: fp8-operand instantiations only
     stamp(3);
     cv = next_valid(cv + G);
     if (cv < 0) break;
@@ -1519,7 +1522,7 @@ __global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const Gemm
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       rscv[mi] = 1.0f;
-      if (EPI == 1 && p.rs_ssq) {
+      if ((EPI == 1 || EPI == 5) && p.rs_ssq) {
         const int mr = m0 + wm * (MI * 32) + mi * 32 + tl31;
         rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
       }
@@ -1812,11 +1815,15 @@ int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
   int epi = 0;
   if (a.rb == 0) {
     if (d.wide8 && !a.mul && !a.res && !a.resT && !a.ssq_out) epi = 1;
-    else if (d.wide8 && a.mul && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
+    else if (d.wide8 && a.mul && a.outT && !a.out8 && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
     else if (!d.wide8 && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;   // fp32 (+ operand-type) output, with or without a residual
     else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
   }
   if (a.resT && epi != 4) return -1;   // one-tile-per-workgroup kernel
+  if (a.hm_D) {   // head-major output: its own instantiation (as a run-time branch of EPI 1 it cost every row-major launch ~9 %)
+    if (epi != 1 || a.act != ACT_NONE) return (int)hipErrorInvalidValue;
+    return launch_persistent_inst<ACT_NONE, 5>(d, grid, st);
+  }
   switch (a.act * 8 + epi) {
     case ACT_NONE * 8 + 1: return launch_persistent_inst<ACT_NONE, 1>(d, grid, st);
     case ACT_NONE * 8 + 3: return launch_persistent_inst<ACT_NONE, 3>(d, grid, st);
@@ -1842,7 +1849,7 @@ int launch_pp_inst2(const GemmDev& d, int grid, hipStream_t st) {
 }
 template <int ACT, int EPI>
 int launch_pp_inst(const GemmDev& d, int grid, hipStream_t st) {
-  if constexpr (EPI == 1 || EPI == 4) {     // the fp8-activation path exists for the bf16-output and bf16-stream epilogues
+  if constexpr (EPI == 1 || EPI == 4 || EPI == 5) {     // the fp8-activation path exists for the bf16-output and bf16-stream epilogues
     if (d.raster == 8) return launch_pp_inst2<ACT, EPI, true>(d, grid, st);
   } else {
     if (d.raster == 8) return (int)hipErrorInvalidValue;
@@ -1854,7 +1861,7 @@ int launch_pp_inst(const GemmDev& d, int grid, hipStream_t st) {
 // bf16 weights; returns -1 when the problem does not fit it (caller falls back)
 int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
   if (a.a8) { if (!a.w8 || a.K % 256 != 0) return -1; }
-  else if (a.w8 || (a.K / 64) % 2 != 0) return -1;
+  else if (a.w8 || (a.K / 64) % 2 != 0 || a.out8) return -1;   // (an fp8 copy of a bf16-operand GEMM's output: launch_persistent)
   if (g_num_cu == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -1884,11 +1891,15 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
   int epi = 0;
   if (a.rb == 0) {
     if (d.wide8 && !a.mul && !a.res && !a.resT && !a.ssq_out) epi = 1;
-    else if (d.wide8 && a.mul && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
+    else if (d.wide8 && a.mul && a.outT && !a.out8 && !a.res && !a.resT && !a.rs_ssq && !a.ssq_out) epi = 2;
     else if (!d.wide8 && a.out32 && !a.mul && !a.rs_ssq && !a.resT) epi = 3;   // fp32 (+ operand-type) output, with or without a residual
     else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
   }
   if (a.resT && epi != 4) return -1;
+  if (a.hm_D) {   // head-major output: its own instantiation (see launch_persistent)
+    if (epi != 1 || a.act != ACT_NONE) return (int)hipErrorInvalidValue;
+    return launch_pp_inst<ACT_NONE, 5>(d, grid, st);
+  }
   switch (a.act * 8 + epi) {
     case ACT_NONE * 8 + 1: return launch_pp_inst<ACT_NONE, 1>(d, grid, st);
     case ACT_NONE * 8 + 3: return launch_pp_inst<ACT_NONE, 3>(d, grid, st);
@@ -1916,7 +1927,7 @@ int launch_wide_inst(const GemmDev& d, int grid, hipStream_t st) {
 int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
   if (a.w8 || a.rb != 0 || a.batch > 1 || a.M % TileW::BM || a.N % TileW::BN || a.K < 2 * 64 || a.K % 64 || !d.wide8) return -1;
   if ((long long)a.M * a.lda * 2 >= (1LL << 32) || (long long)a.N * a.ldw * 2 >= (1LL << 32)) return -1;
-  if (a.mul || a.res || a.out32) return -1;
+  if (a.mul || a.res || a.out32 || a.hm_D) return -1;
   int epi = 0;
   if (!a.resT && !a.ssq_out) epi = 1;
   else if (a.resT && !a.rs_ssq && a.act == ACT_NONE) epi = 4;
@@ -2178,7 +2189,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
         a.K >= 2 * 64 && gemm_raster(a.tune) == 0 && gemm_epi(a.tune) &&
         a.M % TileL::BM == 0 && a.N % TileL::BN == 0 && (long long)a.M * a.lda * 2 < (1LL << 32) &&
         (long long)a.N * a.ldw * (long long)esw < (1LL << 32)) {
-      const int epi_id = a.resT ? 4 : ((a.res || a.out32) ? 3 : (a.mul ? 2 : 1));
+      const int epi_id = a.hm_D ? 5 : (a.resT ? 4 : ((a.res || a.out32) ? 3 : (a.mul ? 2 : 1)));
       if (gemm_pp(a.tune) || a.a8) {
         const int e = launch_pp(d, a, st);
         if (e >= 0) { if (a.kernel_id) *a.kernel_id = (a.a8 ? 9000 : 1000) + (a.act + 1) * 10 + epi_id; return e; }
