@@ -271,6 +271,8 @@ int vima_t5_bucket(int relative_position);
  *                            "fp8_headroom_pct" [125] VIMA_PRECISION_FP8: scale = pct/100 x max |x| / 448 (>= 100); setting it re-calibrates
  *                            "kv_headmajor" [1] decoder prompt K / V written head-major ([B][2 heads][Lp][head dim]) where the projection runs on the
  *                                               persistent 256x256 GEMM (batch x prompt large enough): same values, contiguous reads in the cross attention
+ *                            "geglu_pair"   [1] a GEGLU whose two products read the same input (the decoder blocks' MLP) as ONE GEMM launch over
+ *                                               block-interleaved weights where the grid is between the dual-accumulator and the 256x256 forms: same values
  *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass

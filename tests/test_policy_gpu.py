@@ -743,3 +743,38 @@ def test_head_major_prompt_kv_cache_is_bit_identical():
     stateless, _ = run(1, False)
     for i in range(3):
         assert torch.equal(stateless[i], ref[i]), i
+
+
+@pytest.mark.parametrize("size,B,Ts", [("2M", 256, (1, 2)), ("2M", 250, (1,)), ("200M", 256, (1,))])
+def test_geglu_pair_over_interleaved_weights_is_bit_identical(size, B, Ts):
+    """Round 4: the decoder blocks' MLP (components.py:221-226: c_fc GELU'd x gated_layer, both reading ln_1's output) runs as ONE GEMM launch over
+    block-interleaved weights (GemmArgs::pair32, option geglu_pair, default on) where the [rows, 4E] grid is too large for the dual-accumulator
+    resident form and too small for the persistent 256x256 kernels -- batch 256 x 8 object tokens = 2048 rows, the warm / incremental step of the
+    headline workload. Both factors of an output element sit in one lane's accumulators, and the epilogue applies the operations and roundings of the
+    two-launch form: logits must be equal bit for bit (ragged row count: 250 x 8 rows)."""
+    cfg = syn.config(size, xattn_n_positions=256)
+    sd = syn.make_state_dict(cfg, 5, head_gain=0.5)
+    Lp, Q, E = 64, 8, cfg.embed_dim
+    g = torch.Generator().manual_seed(9)
+    ptok = torch.randn(Lp, B, E, generator=g).to(DEV)
+    pmask = torch.ones(B, Lp, dtype=torch.bool, device=DEV)
+    outs = {}
+    for pair in (0, 1):
+        pol = loaded_policy(cfg, sd, "bf16", geglu_pair=pair)
+        res = []
+        for T in Ts:
+            gi = torch.Generator().manual_seed(100 + T)
+            otok = torch.randn(T, B, Q, E, generator=gi).to(DEV)
+            atok = torch.randn(T - 1, B, E, generator=gi).to(DEV) if T > 1 else None
+            pol.prof_enable(True)
+            res.append(pol.forward(otok, torch.ones(T, B, Q, dtype=torch.bool, device=DEV), atok, ptok, pmask).clone())
+            torch.cuda.synchronize()
+            launches = pol.prof_read_gemm_launches()
+            pol.prof_enable(False)
+            n_pair = sum(1 for l in launches if l["N"] == 8 * E)          # the interleaved weight has 2 x 4E rows
+            assert n_pair == (cfg.xf_n_layers if pair else 0), (pair, T, n_pair)
+        outs[pair] = res
+        del pol
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (a - b).abs().max().item()

@@ -502,6 +502,49 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
       constexpr int RPI = 64 / LPR;                         // rows per wave-instruction
       static_assert(TL::SMEM_BYTES / NW >= 32 * LDE * 4, "per-wave LDS slab for the epilogue");
       float* stage = reinterpret_cast<float*>(smem + w * (TL::SMEM_BYTES / NW));
+      if constexpr (ACT == ACT_GELU && sizeof(T) == 2 && NI == 2 && !W8) {
+        if (p.epi_lds == 2) {
+          // GEGLU PAIR (GemmArgs::pair32): W's rows alternate in blocks of 32 between the GELU'd layer and its plain multiplier, so a lane's
+          // acc[mi][0][r] and acc[mi][1][r] are the two factors of ONE output element: out[m][j] = bf16(gelu(a + bias) * bf16(g + bias)), the
+          // very operations (and roundings) of the multiplier GEMM's bf16 store followed by the GELU GEMM's `mul` epilogue, without the
+          // second launch, the multiplier's store and the per-iteration `mul` loads. A 32-row x 32-column product slab goes through LDS.
+          constexpr int LDP = 32 + 4;
+          const int nout = (n0 >> 1) + wn * 32 + (lane & 3) * 8;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int nl = 8 * q + 4 * hi;
+              const int nb = n0 + wn * WCOLS + nl;
+              float4 a = make_float4(acc[mi][0][4 * q], acc[mi][0][4 * q + 1], acc[mi][0][4 * q + 2], acc[mi][0][4 * q + 3]);
+              float4 g = make_float4(acc[mi][1][4 * q], acc[mi][1][4 * q + 1], acc[mi][1][4 * q + 2], acc[mi][1][4 * q + 3]);
+              if (bias) {
+                const float4 ba = load4(bias + nb), bg = load4(bias + nb + 32);
+                a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w; g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+              }
+              a.x = apply_act_t<T>(a.x, ACT_GELU); a.y = apply_act_t<T>(a.y, ACT_GELU); a.z = apply_act_t<T>(a.z, ACT_GELU); a.w = apply_act_t<T>(a.w, ACT_GELU);
+              const uint32_t g01 = pack2_bf16(g.x, g.y), g23 = pack2_bf16(g.z, g.w);   // the multiplier as the separate launch stores it
+              a.x *= __uint_as_float(g01 << 16); a.y *= __uint_as_float(g01 & 0xffff0000u);
+              a.z *= __uint_as_float(g23 << 16); a.w *= __uint_as_float(g23 & 0xffff0000u);
+              *reinterpret_cast<float4*>(stage + l31 * LDP + nl) = a;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int r = it * 16 + (lane >> 2);
+              const float4 v0 = *reinterpret_cast<const float4*>(stage + r * LDP + (lane & 3) * 8);
+              const float4 v1 = *reinterpret_cast<const float4*>(stage + r * LDP + (lane & 3) * 8 + 4);
+              const int m = m0 + wm * (MI * 32) + mi * 32 + r;
+              if (m < p.M) {
+                uint4 o;
+                o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
+                *reinterpret_cast<uint4*>(outT + (long long)m * p.ldT + nout) = o;
+              }
+            }
+          }
+          stamp(3);
+          return;
+        }
+      }
       const int rr = lane / LPR, cc = (lane % LPR) * 4;
       const int n = n0 + wn * WCOLS + cc;
 #pragma unroll
@@ -1742,7 +1785,7 @@ int launch_tile(GemmDev d, const GemmArgs& a, bool vec, hipStream_t st) {
   d.ntiles = (d.N + TL::BN - 1) / TL::BN;
   const int groups = (d.mtiles + 7) / 8;
   d.raster = gemm_raster(a.tune);
-  d.epi_lds = gemm_epi(a.tune) || a.ssq_out != nullptr;   // the RMS partial sums exist only in the LDS epilogue
+  d.epi_lds = a.pair32 ? 2 : (gemm_epi(a.tune) || a.ssq_out != nullptr);   // the RMS partial sums exist only in the LDS epilogue; 2 = GEGLU pair
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   {   // n-group: W panels of ~1.5 MB stay resident in one XCD's 4 MiB L2 while its A panels stream through
     const long long panel = (long long)TL::BN * a.K * (long long)sizeof(T);
@@ -2171,8 +2214,17 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       const int e = launch_resident(d, a, 0, st);
       return e >= 0 ? e : (int)hipErrorInvalidValue;
     }
+    if (a.pair32) {   // GEGLU pair over block-interleaved weights: the 128x128 ring tile's pair epilogue (the caller asks gemm_pair_ok() first)
+      if (!v || a.w8 || a.a8 || a.act != ACT_GELU || a.mul || a.res || a.resT || a.out32 || a.out8 || a.ssq_out || a.rs_ssq || a.rb > 0 ||
+          a.batch > 1 || a.hm_D || !a.outT || a.N % TileS::BN != 0 || a.K % 64 != 0 || a.ldT % 8 != 0 || !aligned_to(a.outT, 16) ||
+          !gemm_pair_ok(a.tune, a.M, a.N / 2, a.K))
+        return (int)hipErrorInvalidValue;
+      if (a.kernel_id) *a.kernel_id = 5000 + (a.act + 1) * 10;
+      return launch_tile<T, TileS, true>(d, a, v, st);
+    }
   }
 #endif
+  if (a.pair32) return (int)hipErrorInvalidValue;
   if constexpr (sizeof(T) == 2) {
     // TileL when the 256x256 grid still fills the chip (>= ~1 workgroup per CU) and padding waste is small
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
@@ -2248,6 +2300,20 @@ size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16) {
 }
 int gemm_splitk_enabled(const Tuning* t) { return gemm_splitk(t); }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
+// GEGLU pair over block-interleaved weights (GemmArgs::pair32): for [M, Nout] outputs that would otherwise be two ring-tile launches --
+// neither the dual-accumulator resident form (small grids) nor the persistent 256x256 kernels (large ones)
+int gemm_pair_ok(const Tuning* t, long long M, long long Nout, long long K) {
+#ifdef VIMA_GEMM_LAB
+  return 0;
+#else
+  if (M <= 0 || Nout <= 0 || Nout % 64 != 0 || K < 64 || K % 64 != 0) return 0;
+  if (gemm_tile(t) != 0 || gemm_variant(t) != 1 || !gemm_epi(t) || gemm_raster(t) != 0) return 0;
+  if (gemm_dual_ok(t, (int)M, (int)Nout)) return 0;
+  if (((M + 255) / 256) * ((Nout + 255) / 256) >= 160) return 0;   // `large`: the GELU GEMM takes the persistent kernel's gate epilogue
+  if (gemm_small(t) && ((M + 127) / 128) * ((Nout + 127) / 128) < 128) return 0;   // small grids: 64x64 ring tiles / resident kernel
+  return 1;
+#endif
+}
 int gemm_dual_ok(const Tuning* t, int M, int N) {
   if (!gemm_grouped_ok(t) || M <= 0 || N <= 0 || N % 4 != 0) return 0;
   if (M <= 32) return 1;

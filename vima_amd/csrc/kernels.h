@@ -64,6 +64,11 @@ struct GemmArgs {
   // -- [batch][head][row][hm_D], every head's rows contiguous -- instead of outT[r * ldT + n]. The decoder's prompt K / V cache is written
   // this way so that the split-key cross attention streams 32-KB runs per (batch, head) instead of 64-byte slices of 3-KB rows.
   int hm_D = 0, hm_L = 0;
+  // GEGLU PAIR (pair32 = 1; bf16, act = ACT_GELU, ask gemm_pair_ok() first): W [N, K] and bias [N] hold TWO layers of N / 2 outputs each, alternating in
+  // blocks of 32 rows -- block 2j = rows 32j.. of the GELU'd layer, block 2j + 1 = rows 32j.. of its plain multiplier -- and the output is
+  // outT[m][j] = bf16(gelu(A.W1[j] + b1[j]) * bf16(A.Wg[j] + bg[j])), [M, N / 2]: bit-identical to the multiplier GEMM (bf16 output) followed by the
+  // GELU GEMM with `mul`, in one launch of the 128x128 ring tile (both factors of an output element sit in one lane's accumulators).
+  int pair32 = 0;
   // output-row remap (outputs only): orow = (r / rb) * s_hi + (r % rb) * s_lo + ro ; rb == 0 -> identity
   int rb = 0, s_hi = 0, s_lo = 0, ro = 0;
   // RMS statistics fused into the GEMMs either side of a T5 RMSNorm (the norm's weight is folded into W at pack time):
@@ -108,6 +113,7 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
 size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
 int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
+int gemm_pair_ok(const Tuning* t, long long M, long long Nout, long long K);   // the block-interleaved GEGLU pair (GemmArgs::pair32) is the form to use for an [M, Nout] output
 int gemm_dual_ok(const Tuning* t, int M, int N);   // the DUAL form (GemmArgs::W2) is available for an [M, N] output with this handle's knobs
 int gemm_headmajor_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw, int hm_D, int hm_L, int a8);   // GemmArgs::hm_D / hm_L usable for this problem
 int gemm_a8_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw);   // an fp8-ACTIVATION GEMM (GemmArgs::a8) of this shape is launchable with this handle's knobs

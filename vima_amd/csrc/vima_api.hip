@@ -252,6 +252,7 @@ struct VimaHandle {
   std::map<int, float*> t5_bias_tables;          // L -> device [12][2L-1]
   std::map<int, int> t5_bias_far;                // L -> distance from which that table is constant on both sides (AttnArgs::bias_far; 0: never)
   int op_bias_far = 0;                           // option "op_bias_far": AttnArgs::bias_far of vima_op_attention calls (tests)
+  int geglu_pair = 1;                            // option "geglu_pair": GEGLU layers whose two products read the same input run as ONE launch over block-interleaved weights where gemm_pair_ok()
   int kv_headmajor = 1;                          // option "kv_headmajor": write the decoder's prompt K / V head-major where the projection GEMM allows it
   bool kv_hm = false;                            // layout of the prompt K / V CACHE as built (kv_cache_mode 1): [B][2 Hx][Lp][D] instead of [B * Lp][2E]
   Lin t5_post; bool has_t5_post = false;
@@ -259,6 +260,7 @@ struct VimaHandle {
   struct DecLayer {
     float *xln_g, *xln_b, *xln2_g, *xln2_b; Lin q, kv, ao, l1, gate, l2;
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b; Lin c_attn, c_proj, fc, mgate, mproj;
+    Lin fc_pair;   // fc and mgate block-interleaved (GemmArgs::pair32); bf16 weights only
   };
   std::vector<DecLayer> dec;
   Lin head1; void* head2_W = nullptr; float* head2_b = nullptr; Lin head3[kNumHeadsOut];
@@ -361,6 +363,28 @@ struct Packer {
     const HostParam* w = get(prefix + wname, {N, K});
     if (w) pack_w(l, w->data);
     if (bias) l.b = vec(prefix + ".bias", N);
+    return l;
+  }
+  // GEGLU pair (GemmArgs::pair32): the GELU'd Conv1D layer [K, N] (+ bias) and its bias-less nn.Linear multiplier [N, K] as ONE [2N, K] weight,
+  // alternating in blocks of 32 output rows (block 2j: GELU'd rows 32j.., block 2j + 1: multiplier rows 32j..); the multiplier's bias entries are 0
+  Lin pair32(const std::string& conv_prefix, const std::string& lin_prefix, int N, int K) {
+    Lin l;
+    l.N = 2 * N; l.K = K;
+    const HostParam* w1 = get(conv_prefix + ".weight", {K, N});
+    const HostParam* b1 = get(conv_prefix + ".bias", {N});
+    const HostParam* wg = get(lin_prefix + ".weight", {N, K});
+    if (!w1 || !b1 || !wg) return l;
+    std::vector<float> t((size_t)2 * N * K), bb((size_t)2 * N, 0.0f);
+    for (int n = 0; n < N; ++n) {
+      const size_t r1 = (size_t)(n / 32) * 64 + (n % 32), rg = r1 + 32;
+      for (int k = 0; k < K; ++k) {
+        t[r1 * K + k] = w1->data[(size_t)k * N + n];
+        t[rg * K + k] = wg->data[(size_t)n * K + k];
+      }
+      bb[r1] = b1->data[n];
+    }
+    l.W = up_T(t);
+    l.b = up_f32(bb.data(), bb.size());
     return l;
   }
   // HF Conv1D weight [K(in), N(out)] -> packed [N,K]
@@ -546,6 +570,7 @@ int pack_all(VimaHandle* h) {
     D.fc = P.conv1d(b + "mlp.c_fc", 4 * E, E);
     D.mproj = P.conv1d(b + "mlp.c_proj", E, 4 * E);
     D.mgate = P.linear(b + "mlp.gated_layer", 4 * E, E, false);
+    if (h->bf16 && !h->w8 && (4 * E) % 64 == 0) D.fc_pair = P.pair32(b + "mlp.c_fc", b + "mlp.gated_layer", 4 * E, E);
   }
   // ---- action decoder: 12 MLPs E->512->512->bins (action_decoder.py:128-166), layer 1 stacked, layer 2 batched
   {
@@ -740,7 +765,13 @@ struct Run {
   // u = GELU(A1 . L1^T + b1) * bf16(A2 . Lg^T): the value / gate pair of a GEGLU (components.py:31-33, 221-226). ONE dual-accumulator
   // launch where the library has one for this shape (bf16 weights, underfilled grid: batch <= ~32), else the gate GEMM into `g` followed
   // by the value GEMM with the gate as its epilogue multiplier -- bit-identical either way
-  int geglu(const void* A1, const Lin& L1, const void* A2, const Lin& Lg, int M, void* g, void* u) {
+  int geglu(const void* A1, const Lin& L1, const void* A2, const Lin& Lg, int M, void* g, void* u, const Lin* pair = nullptr) {
+    if (pair && pair->W && A1 == A2 && h->geglu_pair && h->bf16 && pair->N == 2 * L1.N && gemm_pair_ok(&h->tune, M, L1.N, L1.K)) {
+      GemmArgs a;   // one launch over the block-interleaved weights (the grid is neither small enough for the dual form nor large enough for the 256x256 kernels)
+      a.A = A1; a.lda = L1.K; setW(a, *pair); a.M = M; a.N = pair->N; a.K = L1.K; a.bias = pair->b; a.act = ACT_GELU; a.outT = u; a.ldT = L1.N;
+      a.pair32 = 1;
+      return gemm(a);
+    }
     if (h->bf16 && !L1.ws && !Lg.ws && L1.N == Lg.N && L1.K == Lg.K && gemm_dual_ok(&h->tune, M, L1.N)) {
       GemmArgs a;
       a.A = A1; a.lda = L1.K; setW(a, L1); a.A2 = A2; a.lda2 = Lg.K; a.W2 = Lg.W; a.ldw2 = Lg.K;
@@ -1590,6 +1621,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
   else if (k == "op_stream_T") h->op_stream_T = (int)value;
   else if (k == "op_bias_far") h->op_bias_far = (int)value;
+  else if (k == "geglu_pair") h->geglu_pair = (int)value;
   else if (k == "kv_headmajor") { h->kv_headmajor = (int)value; h->kv_valid = false; }   // the next decode rebuilds the cache in the chosen layout
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
@@ -2020,7 +2052,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     R.attn(s, h->attn_impl);
     R.linear(ctx, E, D.c_proj, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, nullptr, 0);   // x + a
     R.ln(a32, E, D.ln1_g, D.ln1_b, 1e-5f, 0, rq, E, n32, nT);                           // n = ln_1(x + a)
-    R.geglu(nT, D.fc, nT, D.mgate, rq, g, u);
+    R.geglu(nT, D.fc, nT, D.mgate, rq, g, u, &D.fc_pair);
     R.linear(u, 4 * E, D.mproj, rq, ACT_NONE, nullptr, 0, n32, E, a32, E, nullptr, 0);  // n + m
     R.ln(a32, E, D.ln2_g, D.ln2_b, 1e-5f, 0, rq, E, x32, xT);                           // h = ln_2(n + m)
     if (R.err) return R.err;
