@@ -295,8 +295,9 @@ int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], dou
  * residual, write the fp32 stream [+ operand-type copy + RMS partials]: the HBM-heavy ones), 1 = attention, 2 = other. */
 int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]);
 /* The GEMM launches recorded since vima_prof_enable, grouped by the KERNEL the launcher chose: ids[i] = kind * 1000 +
- * (activation + 1) * 10 + epilogue, kind 1 gemm_pp_kernel<ACT, EPI>, 2 gemm_persistent_kernel<ACT, EPI>, 3 gemm_wide_kernel,
- * 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile, 8 two-pass split-K, 10..12 gemm_resident_kernel with the
+ * (activation + 1) * 10 + epilogue (1 bf16 output, 2 GEGLU gate, 3 fp32 output +- residual, 4 bf16 residual stream, 5 bf16 output written head-major),
+ * kind 1 gemm_pp_kernel<ACT, EPI>, 2 gemm_persistent_kernel<ACT, EPI>, 3 gemm_wide_kernel,
+ * 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile (kind 5 with N = 8 x embed_dim: the block-interleaved GEGLU pair, two products per launch), 8 two-pass split-K, 10..12 gemm_resident_kernel with the
  * 32x32 / 64x32 / 64x64 tile (also the grouped launch of the action head's last layers), 15 / 16 its GEGLU-pair form (two products per launch:
  * 32x32 / 64x64 tile); per kernel the summed milliseconds,
  * launches, algorithmic FLOPs and algorithmic HBM bytes. Returns the number of kernels (<= max_n) or a negative error; does
