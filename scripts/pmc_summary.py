@@ -10,6 +10,7 @@ sequence, so the GEMM dispatches of the trace are that sequence repeated; a kern
 usage: python scripts/pmc_summary.py <fetch.db> <write.db> <out.md> <out.json> [launch_log.json]
        (bench.py imports summarise() for its live collection)"""
 import json
+import re
 import sqlite3
 import sys
 
@@ -21,12 +22,23 @@ def short(name):
     return s.split("(")[0][:100]
 
 
-def _norm(name):
-    """kernel name reduced to what both sides agree on: rocprofv3 prints template arguments in full, the library's log abbreviates some"""
-    s = short(name).replace(" ", "")
-    for a, b in (("unsignedshort,", ""), ("vima::", "")):
-        s = s.replace(a, b)
-    return s
+def _sig(name):
+    """what identifies a GEMM kernel in BOTH spellings -- rocprofv3 prints every template argument, the library's launch log abbreviates the tile kernels
+    ("vima::gemm_kernel<Tile<128, 128>> act 0"): (base name, tile rows x columns or None, leading template arguments or the activation)"""
+    s = short(name)
+    base = re.match(r"(?:vima::)?(\w+)", s).group(1)
+    t = re.search(r"R?Tile<\s*(\d+),\s*(\d+)", s)
+    if t:
+        a = re.search(r"act\s*(-?\d+)", s) or re.search(r"Tile<[^>]*>\s*,\s*(-?\d+)", s)
+        return base, (int(t.group(1)), int(t.group(2))), (a.group(1),) if a else ()
+    args = re.search(r"<([^>]*)>", s)
+    return base, None, tuple(x.strip() for x in args.group(1).split(",")) if args else ()
+
+
+def _same_kernel(a, b):
+    (ba, ta, aa), (bb, tb, ab) = _sig(a), _sig(b)
+    n = min(len(aa), len(ab))
+    return ba == bb and (ta == tb or ta is None or tb is None) and aa[:n] == ab[:n]
 
 
 def per_dispatch(db, counter):
@@ -86,7 +98,7 @@ def per_shape(fd, wd, log):
     acc = {}
     for i, ((kf, vf), (kw, vw)) in enumerate(zip(fs, ws)):
         e = log[i % L]
-        if _norm(e["kernel"]).split("<")[0] not in _norm(kf) or _norm(kf) != _norm(kw):
+        if not _same_kernel(e["kernel"], kf) or short(kf) != short(kw):
             return None, f"dispatch {i}: trace kernel {short(kf)} vs logged {e['kernel']} (write pass: {short(kw)}): sequence mismatch"
         key = (short(kf), e["M"], e["N"], e["K"])
         a = acc.setdefault(key, [0, 0.0, 0.0])

@@ -135,3 +135,77 @@ def test_obj_inputs_accept_the_reference_datadict():
     for xs, ys in zip(pol._obj_inputs(dd_img, 1)[:3], pol._obj_inputs(imgs, 1)[:3]):
         for x, y in zip(xs, ys):
             assert torch.equal(x, y)
+
+
+def _pmc_db(path, counter, rows):
+    """a rocprofv3-like rocpd database reduced to what scripts/pmc_summary.py reads: counters_collection(dispatch_id, kernel_name, counter_name, value)"""
+    import sqlite3
+    c = sqlite3.connect(path)
+    c.execute("create table counters_collection (dispatch_id integer, kernel_name text, counter_name text, value real)")
+    for i, (k, v) in enumerate(rows):
+        for part in (0.5 * v, 1.5 * v):                     # several rows per dispatch (one per XCD in the real tool): the dispatch's value is their mean
+            c.execute("insert into counters_collection values (?, ?, ?, ?)", (i + 1, k, counter, part))
+    c.commit()
+    c.close()
+
+
+def test_pmc_summary_attributes_traffic_to_gemm_shapes_by_dispatch_order(tmp_path):
+    """bench.py's live `roofline.traffic_per_shape` (scripts/pmc_summary.py): per-dispatch FETCH_SIZE / WRITE_SIZE values of two separate passes are joined by
+    position with the GEMM launch log of one step; read bytes carry the gfx950 half-count correction (2 x FETCH_SIZE KiB); any disagreement between the trace
+    and the log voids the attribution instead of guessing."""
+    import importlib.util
+    import json
+    import os
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(os.path.dirname(__file__), "..", "scripts", "pmc_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    pp1 = "void vima::(anonymous namespace)::gemm_pp_kernel<0, 1, false>(vima::(anonymous namespace)::GemmDev)"
+    pp4 = "void vima::(anonymous namespace)::gemm_pp_kernel<0, 4, false>(vima::(anonymous namespace)::GemmDev)"
+    ln = "void vima::(anonymous namespace)::layernorm_rows2_kernel<3>(float const*)"
+    step = [(pp1, 1000.0), (ln, 10.0), (pp4, 3000.0), (pp1, 2000.0)]           # KiB per dispatch; the non-GEMM kernel is skipped by the join
+    fetch, write = str(tmp_path / "f.db"), str(tmp_path / "w.db")
+    _pmc_db(fetch, "FETCH_SIZE", step + step)                                    # two steps in the trace
+    _pmc_db(write, "WRITE_SIZE", [(k, v / 2) for k, v in step + step])
+    log = [{"kernel": "vima::gemm_pp_kernel<0, 1, false>", "M": 256, "N": 2304, "K": 768},
+           {"kernel": "vima::gemm_pp_kernel<0, 4, false>", "M": 256, "N": 768, "K": 3072},
+           {"kernel": "vima::gemm_pp_kernel<0, 1, false>", "M": 256, "N": 1536, "K": 768}]
+    lp = str(tmp_path / "log.json")
+    json.dump(log, open(lp, "w"))
+    s = ps.summarise(fetch, write, lp)
+    assert s["per_shape"] is not None, s["per_shape_note"]
+    by = {(r["M"], r["N"], r["K"]): r for r in s["per_shape"]}
+    assert set(by) == {(256, 2304, 768), (256, 768, 3072), (256, 1536, 768)}
+    r = by[(256, 768, 3072)]
+    assert r["launches_per_step"] == 1 and r["kernel"].startswith("vima::gemm_pp_kernel<0, 4")
+    assert abs(r["fetch_mb"] - 2 * 3000.0 * 1024 / 1e6) < 1e-9 and abs(r["write_mb"] - 1500.0 * 1024 / 1e6) < 1e-9
+    assert abs(r["bytes_per_launch"] - (2 * 3000.0 + 1500.0) * 1024) < 1e-6
+    assert abs(by[(256, 1536, 768)]["bytes_per_launch"] - (2 * 2000.0 + 1000.0) * 1024) < 1e-6          # same kernel, different shape: kept apart
+    assert s["gemm_bf16_launches"] == 6
+    assert abs(s["gemm_bf16_bytes_per_launch"] - (2 * 2000.0 + 1000.0) * 1024) < 1e-6                    # mean over the six GEMM dispatches
+    # the two spellings of one kernel: rocprofv3's full template arguments against the library's launch-log names (VIMAPolicy._gemm_kernel_name)
+    V = "void vima::(anonymous namespace)::"
+    same = [("vima::gemm_kernel<Tile<64, 64>> act 0", V + "gemm_kernel<unsigned short, vima::(anonymous namespace)::Tile<64, 64, 2, 2, 128, 4, 2>, 0, true, true, false>(GemmDev)"),
+            ("vima::gemm_kernel<Tile<128, 128>> act 2", V + "gemm_kernel<unsigned short, vima::(anonymous namespace)::Tile<128, 128, 2, 2, 128, 2, 2>, 2, true, true, false>(GemmDev)"),
+            ("vima::gemm_kernel<Tile<128, 128>> act -1", V + "gemm_kernel<float, vima::(anonymous namespace)::Tile<128, 128, 2, 2, 128, 2, 2>, -1, false, true, false>(GemmDev)"),
+            ("vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>> act 0", V + "gemm_resident_kernel<vima::(anonymous namespace)::RTile<64, 64, 2, 2, 2, false>, 0>(GemmDev)"),
+            ("vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 1, true>> (GEGLU pair) act 2", V + "gemm_resident_kernel<vima::(anonymous namespace)::RTile<64, 64, 2, 2, 1, true>, 2>(GemmDev)"),
+            ("vima::gemm_persistent_kernel<0, 4>", V + "gemm_persistent_kernel<0, 4, false>(GemmDev)"),
+            ("vima::gemm_pp_kernel<0, 5, false>", pp1.replace("<0, 1,", "<0, 5,")), ("vima::gemm_pp_kernel<0, 1, true>", pp1.replace("false", "true"))]
+    for a, b in same:
+        assert ps._same_kernel(a, b), (a, b)
+    differ = [("vima::gemm_pp_kernel<0, 1, false>", pp4), ("vima::gemm_pp_kernel<0, 1, true>", pp1), ("vima::gemm_kernel<Tile<64, 64>> act 0", same[1][1]),
+              ("vima::gemm_kernel<Tile<128, 128>> act 0", same[1][1]), ("vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>> act 0", same[0][1])]
+    for a, b in differ:
+        assert not ps._same_kernel(a, b), (a, b)
+    # a log that does not match the trace (wrong kernel at position 1) or does not divide it: no attribution, and the note says why
+    bad = [log[0], dict(log[0]), log[2]]
+    json.dump(bad, open(lp, "w"))
+    s2 = ps.summarise(fetch, write, lp)
+    assert s2["per_shape"] is None and "mismatch" in s2["per_shape_note"]
+    json.dump(log + log[:1], open(lp, "w"))
+    s3 = ps.summarise(fetch, write, lp)
+    assert s3["per_shape"] is None and "not a multiple" in s3["per_shape_note"]
+    # the markdown writer accepts both outcomes
+    ps.write_md(s, str(tmp_path / "a.md"))
+    ps.write_md(s3, str(tmp_path / "b.md"))
+    assert "Per GEMM shape" in open(tmp_path / "a.md").read() and "Per-shape attribution" in open(tmp_path / "b.md").read()
