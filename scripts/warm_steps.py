@@ -45,7 +45,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        warm() if mode == "warm" else inc(1 + i % 8)
+        if mode == "warm":
+            warm()
+        else:
+            t = 1 + i % 40                                # steps 1 .. 40 of an episode (n_positions bounds the history), then a new one
+            if t == 1 and i > 0:
+                inc(0)
+            inc(t)
     torch.cuda.synchronize()
     print(f"{mode} batch {B}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per step")
 

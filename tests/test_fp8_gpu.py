@@ -181,3 +181,68 @@ def test_fp8_calibration_has_headroom_and_refuses_non_finite_maxima():
     with pytest.raises(Exception, match="non-finite"):
         bad.forward_prompt_assembly(p)
     assert bad.fp8_act_scales() is None
+
+
+def test_fp8_benchmarked_shape_200m_lp1024_against_reference_golden(golden_dir):
+    """`lp1024_fp8` in the bench record (VIMA-200M, 1024-token prompt, 81 % of the FLOPs on the fp8 MFMA) was never
+    compared with the reference at that size WITH the fp8-activation kernels engaged -- the `lp1024_200M` golden is a batch of 2, which stays
+    on the fp8w kernels (test_fp8_small_batches_fall_back_to_fp8w_kernels). Samples are independent, so the golden's two samples are rows
+    0-1 of a batch of 64 here (65 536 prompt rows, 2 x 16 384 prompt crops: the T5 stack, the ViT chunks and the prompt K/V projections all
+    clear the >= 160-tile bar, exactly like the benchmarked batch of 256); call 2 runs the fp8 kernels (asserted from the launch profile) and
+    rows 0-1 are compared with what the UNMODIFIED reference computed (tests/golden/lp1024_200M.npz), gated against the error the fake-quant
+    oracle -- same weights, same scales, same quantisation points -- has against that golden."""
+    import os
+    import numpy as np
+    from oracle.cases import build_case, case_state_dict
+    gold = np.load(os.path.join(golden_dir, "lp1024_200M.npz"))
+    cfg, wseed, p_gold, o_gold, _ = build_case("lp1024_200M")
+    sd = case_state_dict("lp1024_200M", cfg)
+    B = 64
+    p_fill = syn.make_prompt(B - 2, n_segments=64, words_per_segment=8, q_per_view=4, seed=7001)
+    o_fill = syn.make_obs(1, B - 2, 4, seed=7002)
+    prompts, obs = syn.concat_prompts(p_gold, p_fill), syn.concat_obs(o_gold, o_fill)
+    pol = loaded_policy(cfg, sd, "fp8")                    # default options: the benchmarked path (dual_stream on)
+    p, o = syn.to_device(prompts, DEV), syn.to_device(obs, DEV)
+    ptok, pmask = pol.forward_prompt_assembly(p)           # call 1 calibrates T5 + ViT (fp8w kernels)
+    _logits(pol, ptok, pmask, o)                           # ... and the K/V projection
+    ts, vs, ks = pol.fp8_act_scales("t5"), pol.fp8_act_scales("vit"), pol.fp8_act_scales("kv")
+    assert ts is not None and vs is not None and ks is not None, "the benchmarked shape must be fp8-eligible in all three groups"
+    pol.prof_enable(True)
+    ptok, pmask = pol.forward_prompt_assembly(p)           # call 2: fp8 activations
+    pol.cache_prompt_kv = False                            # stateless decode: the K/V projections run (and are profiled) in this call
+    lg = _logits(pol, ptok, pmask, o)
+    torch.cuda.synchronize()
+    kernels = pol.prof_read_gemm_kernels()
+    pol.prof_enable(False)
+    f8 = {k: v for k, v in kernels.items() if k.endswith(", true>")}
+    n8 = sum(v["launches"] for v in f8.values())
+    fl8, fl = sum(v["flops"] for v in f8.values()), sum(v["flops"] for v in kernels.values())
+    # T5: 12 layers x (qkv, o, wi, wo) on each of the two batch halves (dual_stream) + two ViT chunks of 16 384 crops x 17 + one K/V projection per layer
+    assert n8 == 2 * 48 + 2 * 17 + cfg.xf_n_layers, (n8, list(kernels))
+    assert fl8 / fl > 0.75, fl8 / fl                                  # the record's "81 % of the FLOPs on the fp8 MFMA"
+    ref_lg = torch.from_numpy(gold["raw_logits"])[0]                  # [2, 700]
+    got_lg = lg[:2].float().cpu()
+    assert torch.isfinite(lg).all()
+    assert torch.equal(pmask[:2].cpu(), torch.from_numpy(gold["prompt_masks"]))
+    with torch.no_grad():
+        orc8 = make_fp8_act_oracle(sd, ts, vit_scales=vs, kv_scale=float(ks[0]), **cfg.ctor_kwargs())
+        orc8.fq_vit = True
+        r_ptok, r_pmask = orc8.forward_prompt_assembly(p_gold)
+        orc8.fq_vit = False                                           # one observation's ViT keeps bf16 activations in the library
+        rt, rm = orc8.forward_obs_token(o_gold)
+        r_lg = orc8.action_logits(orc8.forward(rt, rm, None, r_ptok, r_pmask)[-1])
+
+    def rms(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+    e_lib, e_orc = max_abs(got_lg, ref_lg), max_abs(r_lg, ref_lg)
+    r_lib, r_orc, r_cross = rms(got_lg, ref_lg), rms(r_lg, ref_lg), rms(got_lg, r_lg)
+    from oracle.cases import gold_view
+    t_lib = rms(gold_view("lp1024_200M", "prompt_tokens", ptok[:, :2]).float().cpu(), torch.from_numpy(gold["prompt_tokens"]))
+    t_orc = rms(gold_view("lp1024_200M", "prompt_tokens", r_ptok), torch.from_numpy(gold["prompt_tokens"]))
+    print(f"[fp8 @ VIMA-200M, Lp = 1024, batch {B}, {n8} launches of gemm_pp_kernel<.., true> = {fl8 / fl:.1%} of the GEMM FLOPs] rows 0-1 vs the "
+          f"REFERENCE golden: max|logit err| library {e_lib:.3e}, fake-quant oracle {e_orc:.3e} (max|logit| {ref_lg.abs().max():.3g}); relative RMS "
+          f"library {r_lib:.3e}, oracle {r_orc:.3e}, library vs oracle {r_cross:.3e}; prompt tokens relative RMS library {t_lib:.3e}, oracle {t_orc:.3e}")
+    assert r_lib < 1.25 * r_orc + 5e-3, (r_lib, r_orc)
+    assert t_lib < 1.25 * t_orc + 5e-3, (t_lib, t_orc)
+    assert e_lib < 1.25 * e_orc + 1e-3, (e_lib, e_orc)

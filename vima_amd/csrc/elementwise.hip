@@ -69,6 +69,80 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
   }
 }
 
+// TWO LayerNorms in a row on fp32 rows: y = LN_a(x) -> out32 / outT (the decoder block's post-LN ln_2, components.py:37), then
+// z = LN_b(y) -> out2T (the NEXT layer's XAttention pre-LN of its queries, components.py:166) while the row is still in registers.
+// Same lane mapping, same reduction order and same arithmetic as two launches of layernorm_kernel (the second would re-read the fp32 y
+// this kernel holds): bit-identical, one launch and one 3-KB row round trip fewer per decoder layer.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ in, long long ldin, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, const float* __restrict__ gamma2,
+                                                          const float* __restrict__ beta2, float eps2, int rows, int E, float* out32, T* outT,
+                                                          T* out2T) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + (long long)row * ldin;
+  const int nv = E >> 2;
+  float4 v[LN_MAXV];
+  auto stats = [&](float& mean, float& rstd, float e) {   // layernorm_kernel's two passes
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + i * 64 < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + i * 64 < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    rstd = rsqrtf(wave_sum(q) / (float)E + e);
+  };
+  auto apply = [&](float mean, float rstd, const float* g_, const float* b_) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 g = *reinterpret_cast<const float4*>(g_ + c * 4);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x;
+        o.y = (v[i].y - mean) * rstd * g.y;
+        o.z = (v[i].z - mean) * rstd * g.z;
+        o.w = (v[i].w - mean) * rstd * g.w;
+        if (b_) {
+          const float4 bb = *reinterpret_cast<const float4*>(b_ + c * 4);
+          o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+        }
+        v[i] = o;
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < nv ? load4(x + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float mean, rstd;
+  stats(mean, rstd, eps);
+  apply(mean, rstd, gamma, beta);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      if (out32) store4(out32 + (long long)row * E + c * 4, v[i]);
+      if (outT) store4(outT + (long long)row * E + c * 4, v[i]);
+    }
+  }
+  stats(mean, rstd, eps2);
+  apply(mean, rstd, gamma2, beta2);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) store4(out2T + (long long)row * E + c * 4, v[i]);
+  }
+}
+
 // bf16 -> bf16 (+ optional e4m3) LayerNorm over rows of E = 256 * NV elements, the shape of the ViT / decoder stream LayerNorms of a
 // big batch (46 launches of 180 MB per B = 256 step). HALF a wave owns a row: every lane loads NV 16-byte chunks (the one-wave-per-row
 // kernel above issues 8-byte loads and retires a wave per row: 4.1 TB/s), a wave walks row pairs with a grid-sized stride and has the
@@ -623,6 +697,19 @@ int launch_layernorm(const float* in, long long ldin, const float* gamma, const 
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, rms,
                        rows, E, out32, (float*)outT);
+  return (int)hipGetLastError();
+}
+
+int launch_layernorm2(const float* in, long long ldin, const float* gamma, const float* beta, float eps, const float* gamma2,
+                      const float* beta2, float eps2, int rows, int E, float* out32, void* outT, void* out2T, bool is_bf16, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (E % 4 != 0 || E > 64 * 4 * LN_MAXV || ldin % 4 != 0 || !out2T) return (int)hipErrorInvalidValue;
+  if (is_bf16)
+    hipLaunchKernelGGL(layernorm2_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, gamma2, beta2, eps2,
+                       rows, E, out32, (bf16_t*)outT, (bf16_t*)out2T);
+  else
+    hipLaunchKernelGGL(layernorm2_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, in, ldin, gamma, beta, eps, gamma2, beta2, eps2,
+                       rows, E, out32, (float*)outT, (float*)out2T);
   return (int)hipGetLastError();
 }
 

@@ -214,6 +214,28 @@ __device__ __forceinline__ float rms_row_scale(const float* ssq, int parts, int 
   return __builtin_amdgcn_rsqf(t * invk + eps);
 }
 
+// fused LayerNorm (mean AND variance): mean and 1 / sqrt(var + eps) of row `row` from the producer's per-32-column partial sums and
+// partial sums of squares (GemmArgs::sum_out / ssq_out), summed in rms_row_scale's fixed order; var = E[x^2] - mean^2 in fp32
+__device__ __forceinline__ float ln_tree24(const float* q) {
+  const float4 a = load4(q), b = load4(q + 4), c = load4(q + 8), d = load4(q + 12), e = load4(q + 16), f = load4(q + 20);
+  const float s0 = a.x + a.y, s1 = a.z + a.w, s2 = b.x + b.y, s3 = b.z + b.w, s4 = c.x + c.y, s5 = c.z + c.w;
+  const float s6 = d.x + d.y, s7 = d.z + d.w, s8 = e.x + e.y, s9 = e.z + e.w, s10 = f.x + f.y, s11 = f.z + f.w;
+  return (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) + ((s8 + s9) + (s10 + s11));
+}
+__device__ __forceinline__ void ln_row_stats(const float* sum, const float* ssq, int parts, int row, float invk, float eps, float& mean, float& rstd) {
+  const float* qs = sum + (long long)row * parts;
+  const float* qq = ssq + (long long)row * parts;
+  float ts, tq;
+  if (parts == 24) { ts = ln_tree24(qs); tq = ln_tree24(qq); }
+  else {
+    ts = 0.f; tq = 0.f;
+    for (int j = 0; j < parts; ++j) { ts += qs[j]; tq += qq[j]; }
+  }
+  mean = ts * invk;
+  const float var = fmaxf(__builtin_fmaf(-mean, mean, tq * invk), 0.0f);
+  rstd = __builtin_amdgcn_rsqf(var + eps);
+}
+
 // sum of squares of 4 consecutive output columns; one fixed fma chain so that every kernel rounds identically (the
 // fused-RMSNorm statistics must not depend on which tile shape produced the row: batch-composition invariance)
 __device__ __forceinline__ float sumsq4(const float4& v) {
@@ -243,6 +265,7 @@ struct GemmDev {
   int rb, s_hi, s_lo, ro;
   int hm_D, hm_L;   // head-major output of the 256x256 bf16-output epilogue (GemmArgs::hm_D / hm_L; 0 = row-major)
   float* ssq_out; const float* rs_ssq; int rs_parts; float rs_invk, rs_eps;
+  float* sum_out; const float* rs_sum; const float* rs_c;   // fused LayerNorm (GemmArgs::sum_out / rs_sum / rs_c)
   const float* wscale;   // fp8 weights: per-output-channel dequantisation scale [N], applied to the accumulator column
   float ascale;          // fp8 ACTIVATIONS (gemm_pp_kernel<.., F8>): the A operand's per-tensor dequantisation scale (x wscale[n])
   void* out8; int ld8; float out8_inv;   // optional fp8 e4m3 copy of the bf16 output: e4m3(value * out8_inv), saturating at 448
@@ -512,12 +535,22 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           const int nout = (n0 >> 1) + wn * 32 + (lane & 3) * 8;
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
+            float mu = 0.f, rsd = 1.f;   // fused LayerNorm of the GELU'd factor's input (GemmArgs::rs_sum): a = rstd * (A.W1' - mean * c) + d
+            if (p.rs_sum) {
+              int mr = m0 + wm * (MI * 32) + mi * 32 + l31; mr = mr < p.M ? mr : p.M - 1;
+              ln_row_stats(p.rs_sum, p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps, mu, rsd);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int nl = 8 * q + 4 * hi;
               const int nb = n0 + wn * WCOLS + nl;
               float4 a = make_float4(acc[mi][0][4 * q], acc[mi][0][4 * q + 1], acc[mi][0][4 * q + 2], acc[mi][0][4 * q + 3]);
               float4 g = make_float4(acc[mi][1][4 * q], acc[mi][1][4 * q + 1], acc[mi][1][4 * q + 2], acc[mi][1][4 * q + 3]);
+              if (p.rs_sum) {
+                const float4 c4 = load4(p.rs_c + nb);
+                a.x = __builtin_fmaf(-mu, c4.x, a.x) * rsd; a.y = __builtin_fmaf(-mu, c4.y, a.y) * rsd;
+                a.z = __builtin_fmaf(-mu, c4.z, a.z) * rsd; a.w = __builtin_fmaf(-mu, c4.w, a.w) * rsd;
+              }
               if (bias) {
                 const float4 ba = load4(bias + nb), bg = load4(bias + nb + 32);
                 a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w; g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
@@ -611,7 +644,7 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           const int r = it * RPI + rr;
           float4 v = *reinterpret_cast<const float4*>(stage + r * LDE + cc);
           const int m = m0 + wm * (MI * 32) + mi * 32 + r;
-          float sq = 0.f;
+          float sq = 0.f, sm = 0.f;
           if (m < p.M && n < p.N) {
             long long orow = m;
             if (p.rb > 0) orow = (long long)(m / p.rb) * p.s_hi + (long long)(m % p.rb) * p.s_lo + p.ro;
@@ -621,10 +654,15 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (out32) store4(out32 + orow * p.ld32 + n, v);
             if (outT) store4(outT + orow * p.ldT + n, v);
             sq = sumsq4(v);
+            sm = (v.x + v.y) + (v.z + v.w);
           }
           if (p.ssq_out) {   // wave-uniform; 8 consecutive lanes hold 32 columns of one row: butterfly, one partial per 32 columns
             sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
             if ((lane & 7) == 0 && m < p.M && n < p.N) p.ssq_out[(long long)m * (p.N >> 5) + (n >> 5)] = sq;
+            if (p.sum_out) {   // fused LayerNorm: the row's partial SUMS as well (same columns, same tree)
+              sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+              if ((lane & 7) == 0 && m < p.M && n < p.N) p.sum_out[(long long)m * (p.N >> 5) + (n >> 5)] = sm;
+            }
           }
         }
       }
@@ -951,6 +989,65 @@ __device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16
   } else {
     if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+  }
+}
+
+// GEGLU PAIR epilogue of the 256x256 tile (GemmArgs::pair32 on gemm_pp_kernel, EPI 6): the weight's rows alternate in blocks of 32 between the GELU'd
+// layer and its plain multiplier, so a lane's acc[mi][0][r] / acc[mi][1][r] are the two factors of ONE output element (the wave's 128x64 block
+// becomes 128x32 outputs). Same operations and roundings as gemm_kernel's pair epilogue (and hence as the two-launch form): out[m][j] =
+// bf16(gelu(a + bias) * bf16(g + bias_g)), with the fused LayerNorm of the GELU'd factor's input (GemmArgs::rs_sum) applied first when HAS_LN.
+// The 32x32 product slab goes through the wave's private LDS slab (the XOR-swizzled layout of tile_epilogue_256_impl) and is stored
+// row-contiguously, 8 bf16 per lane.
+template <bool HAS_LN>
+__device__ __forceinline__ void tile_epilogue_256_pair(const GemmDev& p, const f32x16_t (&acc)[4][2], char* slab, int lane, int m0, int n0, int wm, int wn) {
+  using T = bf16_t;
+  auto fsw = [](int r) { return ((r >> 1) & 1) | ((r & 1) << 1) | (r & 4); };
+  float* stg = reinterpret_cast<float*>(slab);
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+  const int el31 = elane & 31, ehi = elane >> 5;
+  const int fw_ = fsw(el31);
+  const int ccol = (elane & 3) * 8, crow = elane >> 2;     // read-back: 8 columns per lane, 4 lanes per row, 16 rows per instruction
+  T* outT = reinterpret_cast<T*>(p.outT);
+  const int nb0 = n0 + wn * 64 + 4 * ehi;                 // + 8 q: this lane's columns of the GELU'd block (interleaved space); multiplier block: + 32
+  const int nout = (n0 >> 1) + wn * 32 + ccol;
+  // (the column constants -- bias of both factors, the LayerNorm's c -- are re-read per 32-row block from L1: held for the whole tile they are 48
+  // registers on top of the 128 accumulators and the kernel spills; the row statistics are fetched here, not at the start of the tile, for the
+  // same reason -- the pair form runs where a CU owns one or two tiles, so there is no next tile's operand stream to queue behind)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    float mu = 0.f, rsd = 1.f;
+    if constexpr (HAS_LN) ln_row_stats(p.rs_sum, p.rs_ssq, p.rs_parts, m0 + wm * 128 + mi * 32 + el31, p.rs_invk, p.rs_eps, mu, rsd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 a = make_float4(acc[mi][0][4 * q], acc[mi][0][4 * q + 1], acc[mi][0][4 * q + 2], acc[mi][0][4 * q + 3]);
+      float4 g = make_float4(acc[mi][1][4 * q], acc[mi][1][4 * q + 1], acc[mi][1][4 * q + 2], acc[mi][1][4 * q + 3]);
+      if constexpr (HAS_LN) {
+        const float4 c4 = load4(p.rs_c + nb0 + 8 * q);
+        a.x = __builtin_fmaf(-mu, c4.x, a.x) * rsd; a.y = __builtin_fmaf(-mu, c4.y, a.y) * rsd;
+        a.z = __builtin_fmaf(-mu, c4.z, a.z) * rsd; a.w = __builtin_fmaf(-mu, c4.w, a.w) * rsd;
+      }
+      if (p.bias) {
+        const float4 ba = load4(p.bias + nb0 + 8 * q), bg = load4(p.bias + nb0 + 8 * q + 32);
+        a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w; g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+      }
+      a.x = apply_act_t<T>(a.x, ACT_GELU); a.y = apply_act_t<T>(a.y, ACT_GELU); a.z = apply_act_t<T>(a.z, ACT_GELU); a.w = apply_act_t<T>(a.w, ACT_GELU);
+      const uint32_t g01 = pack2_bf16(g.x, g.y), g23 = pack2_bf16(g.z, g.w);   // the multiplier as the separate launch stores it
+      a.x *= __uint_as_float(g01 << 16); a.y *= __uint_as_float(g01 & 0xffff0000u);
+      a.z *= __uint_as_float(g23 << 16); a.w *= __uint_as_float(g23 & 0xffff0000u);
+      *reinterpret_cast<float4*>(stg + el31 * 32 + (((2 * q + ehi) ^ fw_) << 2)) = a;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = it * 16 + crow;
+      const int f = fsw(r);
+      const float4 v0 = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + 0) ^ f) << 2));
+      const float4 v1 = *reinterpret_cast<const float4*>(stg + r * 32 + ((((ccol >> 2) + 1) ^ f) << 2));
+      const long long m = m0 + wm * 128 + mi * 32 + r;
+      uint4 o;
+      o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
+      *reinterpret_cast<uint4*>(outT + m * p.ldT + nout) = o;
+    }
   }
 }
 
@@ -1444,6 +1541,10 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     if (wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stamp(2);
+    if constexpr (EPI == 6) {
+      if (p.rs_sum) tile_epilogue_256_pair<true>(p, acc, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_pair<false>(p, acc, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
+    } else
     tile_epilogue_256<ACT, EPI, F8, F8>(p, acc, rscv, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);   // fp8 copy of the output: fp8-operand instantiations only
     stamp(3);
     cv = next_valid(cv + G);
@@ -1939,6 +2040,10 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
     else if (d.wide8 && a.resT && !a.mul && !a.res && !a.rs_ssq) epi = 4;
   }
   if (a.resT && epi != 4) return -1;
+  if (a.pair32) {   // GEGLU pair over block-interleaved weights (launch_t has validated the form): its own epilogue
+    if (a.a8 || a.act != ACT_GELU) return -1;
+    return launch_pp_inst<ACT_GELU, 6>(d, grid, st);
+  }
   if (a.hm_D) {   // head-major output: its own instantiation (see launch_persistent)
     if (epi != 1 || a.act != ACT_NONE) return (int)hipErrorInvalidValue;
     return launch_pp_inst<ACT_NONE, 5>(d, grid, st);
@@ -2092,6 +2197,7 @@ inline SplitPlan splitk_plan(const GemmArgs& a, bool is_bf16) {
   if (!gemm_splitk(a.tune) || a.w8) return p;
   const int bk = is_bf16 ? 64 : 32;
   if (a.batch > 1 || a.M <= 0 || a.N <= 0 || a.K % bk || a.N % 4 || a.ssq_out || a.rb > 0 || a.resT) return p;
+  if (a.pair32 || a.hm_D || a.W2 || a.grp_col || a.rs_sum || a.sum_out) return p;   // forms whose epilogue the reduce pass does not have
   const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const int slices = a.K / bk;
   if (tiles >= 128 || slices < 24) return p;   // measured: the second pass only pays from K = 1536 (bf16) on
@@ -2165,7 +2271,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.grp_col && (sizeof(T) != 2 || a.w8 || a.a8 || a.act != ACT_NONE || a.mul || a.res || a.resT || a.outT || a.out8 || a.ssq_out || a.rs_ssq ||
                     a.rb > 0 || !a.out32 || a.K % 64 != 0 || !gemm_grouped_ok(a.tune)))
     return (int)hipErrorInvalidValue;
-  if (a.W2 && (sizeof(T) != 2 || a.w8 || a.a8 || a.mul || a.res || a.resT || a.out32 || a.out8 || a.ssq_out || a.rs_ssq || a.rb > 0 || a.batch > 1 ||
+  if (a.W2 && (sizeof(T) != 2 || a.w8 || a.a8 || a.mul || a.res || a.resT || a.out32 || a.out8 || a.ssq_out || (a.rs_ssq && !a.rs_sum) || a.rb > 0 || a.batch > 1 ||
                a.grp_col || !a.outT || !a.A2 || a.K % 64 != 0 || a.N % 4 != 0 || !aligned_to(a.A2, 16) || !aligned_to(a.W2, 16) || (a.lda2 * es) % 16 ||
                (a.ldw2 * es) % 16 || !gemm_dual_ok(a.tune, a.M, a.N)))
     return (int)hipErrorInvalidValue;
@@ -2184,6 +2290,10 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
                  !gemm_headmajor_ok(a.tune, a.M, a.N, a.K, a.lda, a.ldw, a.hm_D, a.hm_L, a.a8)))
     return (int)hipErrorInvalidValue;
   d.ssq_out = a.ssq_out; d.rs_ssq = a.rs_ssq; d.rs_parts = a.rs_parts; d.rs_invk = a.rs_invk; d.rs_eps = a.rs_eps;
+  d.sum_out = a.sum_out; d.rs_sum = a.rs_sum; d.rs_c = a.rs_c;
+  // fused LayerNorm: partial sums ride with the partial sums of squares of an fp32-output producer; the consumers are the two GEGLU-pair forms
+  if (a.sum_out && (sizeof(T) != 2 || !a.ssq_out || !a.out32 || !gemm_lnfold_producer_ok(a.tune, a.M, a.N))) return (int)hipErrorInvalidValue;
+  if (a.rs_sum && (sizeof(T) != 2 || !a.rs_ssq || !a.rs_c || !(a.pair32 || a.W2) || !aligned_to(a.rs_c, 16))) return (int)hipErrorInvalidValue;
   d.wscale = a.w8 ? a.wscale : nullptr;
   d.ascale = a.a8 ? a.ascale : 1.0f;
   d.out8 = a.out8; d.ld8 = a.ld8; d.out8_inv = a.out8_inv;
@@ -2215,10 +2325,15 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       return e >= 0 ? e : (int)hipErrorInvalidValue;
     }
     if (a.pair32) {   // GEGLU pair over block-interleaved weights: the 128x128 ring tile's pair epilogue (the caller asks gemm_pair_ok() first)
-      if (!v || a.w8 || a.a8 || a.act != ACT_GELU || a.mul || a.res || a.resT || a.out32 || a.out8 || a.ssq_out || a.rs_ssq || a.rb > 0 ||
+      if (!v || a.w8 || a.a8 || a.act != ACT_GELU || a.mul || a.res || a.resT || a.out32 || a.out8 || a.ssq_out || (a.rs_ssq && !a.rs_sum) || a.rb > 0 ||
           a.batch > 1 || a.hm_D || !a.outT || a.N % TileS::BN != 0 || a.K % 64 != 0 || a.ldT % 8 != 0 || !aligned_to(a.outT, 16) ||
           !gemm_pair_ok(a.tune, a.M, a.N / 2, a.K))
         return (int)hipErrorInvalidValue;
+      if (gemm_pair_large(a.tune, a.M, a.N / 2, a.K) && (long long)a.M * a.lda * 2 < (1LL << 32) && (long long)a.N * a.ldw * 2 < (1LL << 32)) {
+        d.wide8 = 1;
+        const int e = launch_pp(d, a, st);   // >= 160 full 256x256 tiles of the interleaved [M, 2 Nout] problem: the persistent kernel's pair epilogue
+        if (e >= 0) { if (a.kernel_id) *a.kernel_id = 1000 + (a.act + 1) * 10 + 6; return e; }
+      }
       if (a.kernel_id) *a.kernel_id = 5000 + (a.act + 1) * 10;
       return launch_tile<T, TileS, true>(d, a, v, st);
     }
@@ -2302,6 +2417,16 @@ int gemm_splitk_enabled(const Tuning* t) { return gemm_splitk(t); }
 int gemm_k_multiple(bool is_bf16) { return is_bf16 ? 64 : 32; }
 // GEGLU pair over block-interleaved weights (GemmArgs::pair32): for [M, Nout] outputs that would otherwise be two ring-tile launches --
 // neither the dual-accumulator resident form (small grids) nor the persistent 256x256 kernels (large ones)
+// the interleaved [M, 2 Nout] problem fills the chip with full 256x256 tiles: the pair runs on gemm_pp_kernel<ACT_GELU, 6>
+int gemm_pair_large(const Tuning* t, long long M, long long Nout, long long K) {
+#ifdef VIMA_GEMM_LAB
+  return 0;
+#else
+  if (M <= 0 || Nout <= 0 || M % 256 != 0 || Nout % 128 != 0 || K < 128 || (K / 64) % 2 != 0) return 0;
+  if (gemm_tile(t) != 0 || !gemm_persist(t) || !gemm_pp(t) || gemm_raster(t) != 0 || !gemm_epi(t) || gemm_wide(t) || gemm_variant(t) != 1) return 0;
+  return (M / 256) * (2 * Nout / 256) >= 160 ? 1 : 0;
+#endif
+}
 int gemm_pair_ok(const Tuning* t, long long M, long long Nout, long long K) {
 #ifdef VIMA_GEMM_LAB
   return 0;
@@ -2309,8 +2434,22 @@ int gemm_pair_ok(const Tuning* t, long long M, long long Nout, long long K) {
   if (M <= 0 || Nout <= 0 || Nout % 64 != 0 || K < 64 || K % 64 != 0) return 0;
   if (gemm_tile(t) != 0 || gemm_variant(t) != 1 || !gemm_epi(t) || gemm_raster(t) != 0) return 0;
   if (gemm_dual_ok(t, (int)M, (int)Nout)) return 0;
-  if (((M + 255) / 256) * ((Nout + 255) / 256) >= 160) return 0;   // `large`: the GELU GEMM takes the persistent kernel's gate epilogue
+  if (gemm_pair_large(t, M, Nout, K)) return 1;
+  if (((M + 255) / 256) * ((Nout + 255) / 256) >= 160) return 0;   // `large` without the pair epilogue's shape conditions: the GELU GEMM takes the persistent kernel's gate epilogue
   if (gemm_small(t) && ((M + 127) / 128) * ((Nout + 127) / 128) < 128) return 0;   // small grids: 64x64 ring tiles / resident kernel
+  return 1;
+#endif
+}
+// Fused-LayerNorm PRODUCER (GemmArgs::sum_out): the partial sums exist in the resident kernel's epilogue and in the ring tiles' LDS epilogue, not
+// in the persistent 256x256 kernels' -- i.e. for every [M, N] output that does not take the `large` path
+int gemm_lnfold_producer_ok(const Tuning* t, long long M, long long N) {
+#ifdef VIMA_GEMM_LAB
+  return 0;
+#else
+  if (M <= 0 || N <= 0 || N % 32 != 0) return 0;
+  const int gt = gemm_tile(t);
+  if (gt >= 2 && gt < 7) return 0;
+  if (gt == 0 && ((M + 255) / 256) * ((N + 255) / 256) >= 160) return 0;
   return 1;
 #endif
 }

@@ -81,6 +81,16 @@ struct GemmArgs {
   const float* rs_ssq = nullptr;
   int rs_parts = 0;
   float rs_invk = 0.f, rs_eps = 0.f;
+  // nn.LayerNorm (mean AND variance, affine) folded the same way -- the pre-LN in front of XAttention's feed-forward (components.py:220-226), whose
+  // GEGLU then reads ONE input (the un-normed stream) for both products:
+  //   producer (fp32-output residual GEMM, with ssq_out): sum_out[r][j] = sum over columns [32j, 32j+32) of out[r][n]; ask gemm_lnfold_producer_ok()
+  //   consumer (the GEGLU pair forms, pair32 or W2, with rs_ssq): mean = sum_j rs_sum[r][j] * rs_invk, var = sum_j rs_ssq[r][j] * rs_invk - mean^2,
+  //             and the GELU'd factor's pre-activation becomes rsqrt(var + rs_eps) * (A.W'^T - mean * rs_c[n]) + bias[n], where W' = W diag(gamma) is
+  //             what the caller packed, rs_c[n] = sum_k W'[n][k] (of the ROUNDED operand values) and bias[n] = sum_k beta[k] W[n][k] (+ the layer's bias);
+  //             the plain multiplier factor is untouched. rs_c is indexed like bias (pair32: the interleaved column space).
+  float* sum_out = nullptr;
+  const float* rs_sum = nullptr;
+  const float* rs_c = nullptr;
   // split-K scratch (fp32 [S][M][N] partial products) for grids that would leave most CUs idle; size it with
   // gemm_splitk_bytes(). Without it the launch is a single pass.
   float* splitk_ws = nullptr;
@@ -113,7 +123,9 @@ int launch_gemm(const GemmArgs& a, bool is_bf16, hipStream_t st);
 size_t gemm_splitk_bytes(const GemmArgs& a, bool is_bf16);
 int gemm_splitk_enabled(const Tuning* t);   // the effective split-K setting for a handle
 int gemm_k_multiple(bool is_bf16);  // K must be a multiple of this
+int gemm_pair_large(const Tuning* t, long long M, long long Nout, long long K);   // ... and it will run on the persistent 256x256 kernel's pair epilogue (full tiles, >= 160 of them)
 int gemm_pair_ok(const Tuning* t, long long M, long long Nout, long long K);   // the block-interleaved GEGLU pair (GemmArgs::pair32) is the form to use for an [M, Nout] output
+int gemm_lnfold_producer_ok(const Tuning* t, long long M, long long N);   // GemmArgs::sum_out is available for an [M, N] fp32 output with this handle's knobs
 int gemm_dual_ok(const Tuning* t, int M, int N);   // the DUAL form (GemmArgs::W2) is available for an [M, N] output with this handle's knobs
 int gemm_headmajor_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw, int hm_D, int hm_L, int a8);   // GemmArgs::hm_D / hm_L usable for this problem
 int gemm_a8_ok(const Tuning* t, long long M, long long N, long long K, long long lda, long long ldw);   // an fp8-ACTIVATION GEMM (GemmArgs::a8) of this shape is launchable with this handle's knobs
@@ -124,6 +136,10 @@ int gemm_grouped_ok(const Tuning* t);   // the grouped form (GemmArgs::grp_col) 
 // in: fp32 rows of length E at row stride ldin; outputs optional.
 int launch_layernorm(const float* in, long long ldin, const float* gamma, const float* beta, float eps, int rms,
                      int rows, int E, float* out32, void* outT, bool is_bf16, hipStream_t st);
+// two LayerNorms in a row: y = LN(in; gamma, beta) -> out32 / outT (both optional), z = LN(y; gamma2, beta2) -> out2T (operand type);
+// bit-identical to launch_layernorm twice (the second on the fp32 y)
+int launch_layernorm2(const float* in, long long ldin, const float* gamma, const float* beta, float eps, const float* gamma2,
+                      const float* beta2, float eps2, int rows, int E, float* out32, void* outT, void* out2T, bool is_bf16, hipStream_t st);
 // the same with the input rows in the operand type T (residual stream carried in T)
 // out8 (bf16 mode only): additionally (or, with outT == nullptr, only) the fp8 e4m3 copy e4m3(result * inv8), row stride E bytes
 int launch_layernorm_T(const void* inT, long long ldin, const float* gamma, const float* beta, float eps, int rms, int rows,

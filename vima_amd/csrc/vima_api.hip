@@ -96,6 +96,7 @@ struct Lin {            // packed nn.Linear-layout weight [N,K] (+ optional fp32
   float* b = nullptr;
   int N = 0, K = 0;
   float* ws = nullptr;  // [N] scales; non-null <=> W holds fp8
+  float* c = nullptr;   // [N] fused LayerNorm (GemmArgs::rs_c): sum_k of the ROUNDED operand values of row n of W = W0 diag(gamma)
 };
 
 // fp32 -> OCP FP8 E4M3 (e4m3fn: bias 7, no infinities, max 448), round to nearest even, saturating. Host side of the fp8w
@@ -252,6 +253,8 @@ struct VimaHandle {
   std::map<int, float*> t5_bias_tables;          // L -> device [12][2L-1]
   std::map<int, int> t5_bias_far;                // L -> distance from which that table is constant on both sides (AttnArgs::bias_far; 0: never)
   int op_bias_far = 0;                           // option "op_bias_far": AttnArgs::bias_far of vima_op_attention calls (tests)
+  int ln_fuse = 1;                               // option "ln_fuse": the decoder's ln_2 and the next layer's XAttention pre-LN as ONE launch (layernorm2_kernel), and the pre-LN in front of
+                                                 // XAttention's feed-forward folded into the GEMMs either side of it (GemmArgs::sum_out / rs_sum) where the GEGLU pair forms exist
   int geglu_pair = 1;                            // option "geglu_pair": GEGLU layers whose two products read the same input run as ONE launch over block-interleaved weights where gemm_pair_ok()
   int kv_headmajor = 1;                          // option "kv_headmajor": write the decoder's prompt K / V head-major where the projection GEMM allows it
   bool kv_hm = false;                            // layout of the prompt K / V CACHE as built (kv_cache_mode 1): [B][2 Hx][Lp][D] instead of [B * Lp][2E]
@@ -261,6 +264,9 @@ struct VimaHandle {
     float *xln_g, *xln_b, *xln2_g, *xln2_b; Lin q, kv, ao, l1, gate, l2;
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b; Lin c_attn, c_proj, fc, mgate, mproj;
     Lin fc_pair;   // fc and mgate block-interleaved (GemmArgs::pair32); bf16 weights only
+    // XAttention's feed-forward with its pre-LN folded in (option ln_fuse; bf16 weights only): l1 diag(ln.weight) with bias l1 . ln.bias and the
+    // column sums `c`, alone (small grids: the dual-accumulator form beside `gate`) and block-interleaved with `gate` (pair32 form)
+    Lin xl1g, xl1_pair;
   };
   std::vector<DecLayer> dec;
   Lin head1; void* head2_W = nullptr; float* head2_b = nullptr; Lin head3[kNumHeadsOut];
@@ -385,6 +391,41 @@ struct Packer {
     }
     l.W = up_T(t);
     l.b = up_f32(bb.data(), bb.size());
+    return l;
+  }
+  // nn.Linear [N, K] (no bias) behind a LayerNorm (gamma, beta over K) with the norm folded in: W' = W diag(gamma) in the operand type,
+  // bias'[n] = sum_k beta[k] W[n][k], c[n] = sum_k bf16(W'[n][k]) (the mean term must cancel against what the matrix core actually multiplies).
+  // `gate_prefix` non-empty: block-interleaved in 32-row blocks with that bias-less nn.Linear [N, K] as the plain multiplier (GemmArgs::pair32):
+  // [2N, K], the multiplier's rows carry bias 0 and c 0
+  Lin ln_folded(const std::string& lin_prefix, const std::string& ln_prefix, const std::string& gate_prefix, int N, int K) {
+    Lin l;
+    const bool pair = !gate_prefix.empty();
+    l.N = pair ? 2 * N : N; l.K = K;
+    const HostParam* w = get(lin_prefix + ".weight", {N, K});
+    const HostParam* g = get(ln_prefix + ".weight", {K});
+    const HostParam* b = get(ln_prefix + ".bias", {K});
+    const HostParam* wg = pair ? get(gate_prefix + ".weight", {N, K}) : nullptr;
+    if (!w || !g || !b || (pair && !wg)) return l;
+    std::vector<float> t((size_t)l.N * K), bb((size_t)l.N, 0.0f), cc((size_t)l.N, 0.0f);
+    for (int n = 0; n < N; ++n) {
+      const size_t r1 = pair ? (size_t)(n / 32) * 64 + (n % 32) : (size_t)n;
+      double sb = 0.0, sc = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const float wf = w->data[(size_t)n * K + k] * g->data[k];
+        t[r1 * K + k] = wf;
+        uint32_t u = (uint32_t)h_f2bf(wf) << 16;
+        float wr;
+        memcpy(&wr, &u, 4);
+        sc += (double)wr;
+        sb += (double)b->data[k] * (double)w->data[(size_t)n * K + k];
+        if (pair) t[(r1 + 32) * K + k] = wg->data[(size_t)n * K + k];
+      }
+      bb[r1] = (float)sb;
+      cc[r1] = (float)sc;
+    }
+    l.W = up_T(t);
+    l.b = up_f32(bb.data(), bb.size());
+    l.c = up_f32(cc.data(), cc.size());
     return l;
   }
   // HF Conv1D weight [K(in), N(out)] -> packed [N,K]
@@ -560,6 +601,10 @@ int pack_all(VimaHandle* h) {
     D.l1 = P.linear(x + "linear1", 4 * E, E, false);
     D.gate = P.linear(x + "gated_layer", 4 * E, E, false);
     D.l2 = P.linear(x + "linear2", E, 4 * E, false);
+    if (h->bf16 && !h->w8 && (4 * E) % 64 == 0) {
+      D.xl1g = P.ln_folded(x + "linear1", x + "ln", "", 4 * E, E);
+      D.xl1_pair = P.ln_folded(x + "linear1", x + "ln", x + "gated_layer", 4 * E, E);
+    }
     }
     snprintf(buf, sizeof buf, "%sh.%d.", gp.c_str(), i);
     const std::string b = buf;
@@ -727,7 +772,7 @@ struct Run {
     {   // class 3 = GEMMs whose epilogue adds an fp32 residual and writes the fp32 stream (the HBM-heavy ones); algorithmic
         // bytes = each operand / output / epilogue input once
       const double nb = a.batch > 0 ? a.batch : 1, es = (double)h->esz(), mn = (double)a.M * a.N;
-      const double bytes = nb * ((double)a.M * a.K * es + (double)a.N * a.K * (a.w8 ? 1.0 : es) + (a.out32 ? mn * 4 : 0) + (a.outT ? mn * es : 0) +
+      const double bytes = nb * ((double)a.M * a.K * es + (double)a.N * a.K * (a.w8 ? 1.0 : es) + (a.out32 ? mn * 4 : 0) + (a.outT ? (a.pair32 ? mn / 2 : mn) * es : 0) +
                                  (a.res ? mn * 4 : 0) + (a.resT ? mn * es : 0) + (a.mul ? mn * es : 0) + (a.ssq_out ? (double)a.M * (a.N / 32) * 4 : 0));
       const double two = a.W2 ? 2.0 : 1.0;   // GEGLU pair: two products in one launch
       prof_begin(((a.res && a.out32) || a.resT) ? 3 : 0, two * 2.0 * a.M * (double)a.N * a.K * nb,
@@ -1295,6 +1340,7 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   Run Rb{h, h->aux};
   if (dual && fork_aux(R)) return R.err = 1;
   const long long off1 = (long long)nb[0] * L;      // first row of the second half
+  float* const x1 = x ? x + off1 * kT5Model : nullptr;   // (direct assembly: there is no fp32 stream, and the stream_T layers never touch it)
   const float* ss[2] = {nullptr, nullptr};
   int parts = 1;
   if (direct) {
@@ -1310,7 +1356,7 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     R.other(launch_rms_stats(x, nb[0] * L, kT5Model, buf[0].hT, buf[0].ssB, h->bf16, R.st), "rms_stats");
     ss[0] = buf[0].ssB;
     if (dual) {
-      Rb.other(launch_rms_stats(x + off1 * kT5Model, nb[1] * L, kT5Model, buf[1].hT, buf[1].ssB, h->bf16, Rb.st), "rms_stats");
+      Rb.other(launch_rms_stats(x1, nb[1] * L, kT5Model, buf[1].hT, buf[1].ssB, h->bf16, Rb.st), "rms_stats");
       ss[1] = buf[1].ssB;
     }
   }
@@ -1329,11 +1375,11 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     } else if (fused) {
       float* am = calibrate ? h->fp8_amax + l * 4 : nullptr;
       ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts, am);
-      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts, am);
+      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x1, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts, am);
       parts = kT5Model / 32;
     } else {
       t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
-      if (dual) t5_layer(Rb, h->t5[l], x + off1 * kT5Model, mask + off1, table, nb[1], L, buf[1], h->attn_impl);
+      if (dual) t5_layer(Rb, h->t5[l], x1, mask + off1, table, nb[1], L, buf[1], h->attn_impl);
     }
     if (R.err || Rb.err) return R.err = (R.err ? R.err : Rb.err);
   }
@@ -1343,7 +1389,7 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   if (dual) {
     if (sT) Rb.lnT(buf[1].hT, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
                    out32 ? out32 + off1 * kT5Model : nullptr, outT ? R.offT(outT, off1 * kT5Model) : nullptr);
-    else Rb.ln(x + off1 * kT5Model, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
+    else Rb.ln(x1, kT5Model, h->t5_final, nullptr, 1e-6f, 1, nb[1] * L, kT5Model,
           out32 ? out32 + off1 * kT5Model : nullptr, outT ? R.offT(outT, off1 * kT5Model) : nullptr);
     if (Rb.err) return R.err = Rb.err;
     if (join_aux(R)) return R.err = 1;
@@ -1622,7 +1668,8 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "op_stream_T") h->op_stream_T = (int)value;
   else if (k == "op_bias_far") h->op_bias_far = (int)value;
   else if (k == "geglu_pair") h->geglu_pair = (int)value;
-  else if (k == "kv_headmajor") { h->kv_headmajor = (int)value; h->kv_valid = false; }   // the next decode rebuilds the cache in the chosen layout
+  else if (k == "ln_fuse") h->ln_fuse = (int)value;
+  else if (k == "kv_headmajor") { h->kv_headmajor = (int)value; h->kv_valid = false; h->ep_step = -1; }   // the next decode rebuilds the cache in the chosen layout; a running episode (vima_decode_step) ends: start a new one with step 0
   else if (k == "t5_fuse_rms") h->t5_fuse_rms = (int)value;
   else if (k == "stream_T") h->stream_T = (int)value;
   else if (k == "fp8_headroom_pct") { h->fp8_headroom_pct = value < 100 ? 100 : (int)value; h->fp8_ready = false; h->vit8_ready = false; h->kv8_ready = false; }
@@ -1932,6 +1979,16 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
   void* qkv = R.wsT((size_t)rq * 3 * E);
   float* n32 = R.ws<float>((size_t)rq * E);
   void* nT = R.wsT((size_t)rq * E);
+  // option ln_fuse (bf16 weights): (1) ln_2 of layer i and XAttention's query pre-LN of layer i + 1 are one launch; (2) the pre-LN in front of
+  // XAttention's feed-forward (components.py:220) disappears: attention_out's epilogue leaves per-32-column sums / sums of squares of the new stream
+  // next to it and the feed-forward's GEGLU -- both products now read the UN-normed stream, so it is one launch at every size that has a pair form --
+  // applies mean / rstd to the GELU'd factor in its epilogue (GemmArgs::sum_out / rs_sum / rs_c)
+  const bool lnf = h->ln_fuse != 0 && h->bf16;
+  const int ffold = (lnf && !h->w8 && h->dec[0].xl1g.W && h->dec[0].xl1_pair.W && !gemm_splitk_enabled(&h->tune) && gemm_lnfold_producer_ok(&h->tune, rq, E))
+                        ? (gemm_dual_ok(&h->tune, rq, 4 * E) ? 1 : ((h->geglu_pair && gemm_pair_ok(&h->tune, rq, 4 * E, E)) ? 2 : 0))
+                        : 0;
+  float* st_sum = ffold ? R.ws<float>((size_t)rq * (E / 32)) : nullptr;
+  float* st_ssq = ffold ? R.ws<float>((size_t)rq * (E / 32)) : nullptr;
   if (R.err) return R.err;
   if (inc)
     OTHER(R, launch_dec_embed_step(obs_tok, obs_mask, act_tok, h->pos_emb, h->cfg.n_positions, x32, xT, h->ep_mask, h->ep_poscnt,
@@ -2006,7 +2063,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     auto& D = h->dec[i];
     void* KV = KVs[i];
     // ---- XAttention.forward (components.py:158-228)
-    R.ln(x32, E, D.xln_g, D.xln_b, 1e-5f, 0, rq, E, nullptr, qn);
+    if (i == 0 || !lnf) R.ln(x32, E, D.xln_g, D.xln_b, 1e-5f, 0, rq, E, nullptr, qn);   // (else: written by the previous layer's ln_2 launch)
     R.linear(qn, E, D.q, rq, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, 0, Qb, E);
     if (dual) HIPCK(hipStreamWaitEvent(R.st, h->ev_layer[i], 0));
     else if (build_kv)   // single stream: project right before use (without a cache all layers share one buffer)
@@ -2021,9 +2078,22 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     a.kmask = prompt_mask; a.B = B; a.H = Hx; a.Lq = Lq; a.Lk = Lp; a.D = E / Hx;
     a.scale = 1.0f / sqrtf((float)(E / Hx)); a.mode = ATTN_CROSS;
     R.attn(a, h->attn_impl);
+    if (ffold) {
+      GemmArgs ga;   // a = x + ctx Wo^T -> a32 / aT, + the LayerNorm partials of a32
+      ga.A = ctx; ga.lda = E; R.setW(ga, D.ao); ga.M = rq; ga.N = E; ga.K = E; ga.res = x32; ga.ldres = E; ga.out32 = a32; ga.ld32 = E; ga.outT = aT; ga.ldT = E;
+      ga.ssq_out = st_ssq; ga.sum_out = st_sum;
+      R.gemm(ga);
+      GemmArgs gf;   // u = gelu(LN(a) W1^T) * bf16(a Wg^T), LN folded: both products read aT
+      gf.A = aT; gf.lda = E; gf.M = rq; gf.K = E; gf.act = ACT_GELU; gf.outT = u; gf.ldT = 4 * E;
+      gf.rs_ssq = st_ssq; gf.rs_sum = st_sum; gf.rs_parts = E / 32; gf.rs_invk = 1.0f / (float)E; gf.rs_eps = 1e-5f;
+      if (ffold == 1) { R.setW(gf, D.xl1g); gf.N = 4 * E; gf.bias = D.xl1g.b; gf.rs_c = D.xl1g.c; gf.A2 = aT; gf.lda2 = E; gf.W2 = D.gate.W; gf.ldw2 = E; }
+      else { R.setW(gf, D.xl1_pair); gf.N = 8 * E; gf.bias = D.xl1_pair.b; gf.rs_c = D.xl1_pair.c; gf.pair32 = 1; }
+      R.gemm(gf);
+    } else {
     R.linear(ctx, E, D.ao, rq, ACT_NONE, nullptr, 0, x32, E, a32, E, aT, E);            // + q residual
     R.ln(a32, E, D.xln2_g, D.xln2_b, 1e-5f, 0, rq, E, nullptr, qn);
     R.geglu(qn, D.l1, aT, D.gate, rq, g, u);                                              // gate reads the UN-normed stream
+    }
     R.linear(u, 4 * E, D.l2, rq, ACT_NONE, nullptr, 0, a32, E, x32, E, xT, E);
     // ---- Block.forward (components.py:23-37), post-LN
     AttnArgs s;
@@ -2054,7 +2124,12 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
     R.ln(a32, E, D.ln1_g, D.ln1_b, 1e-5f, 0, rq, E, n32, nT);                           // n = ln_1(x + a)
     R.geglu(nT, D.fc, nT, D.mgate, rq, g, u, &D.fc_pair);
     R.linear(u, 4 * E, D.mproj, rq, ACT_NONE, nullptr, 0, n32, E, a32, E, nullptr, 0);  // n + m
-    R.ln(a32, E, D.ln2_g, D.ln2_b, 1e-5f, 0, rq, E, x32, xT);                           // h = ln_2(n + m)
+    if (lnf && i + 1 < h->cfg.xf_n_layers) {                                             // h = ln_2(n + m) and the next layer's query pre-LN of h
+      auto& Dn = h->dec[i + 1];
+      OTHER(R, launch_layernorm2(a32, E, D.ln2_g, D.ln2_b, 1e-5f, Dn.xln_g, Dn.xln_b, 1e-5f, rq, E, x32, xT, qn, h->bf16, R.st), "layernorm2");
+    } else {
+      R.ln(a32, E, D.ln2_g, D.ln2_b, 1e-5f, 0, rq, E, x32, xT);                         // h = ln_2(n + m)
+    }
     if (R.err) return R.err;
   }
   if (inc) OTHER(R, launch_gather_pred(x32, out, 1, B, Lq, Lq, E, R.st), "gather_pred");   // the last new token of every sample

@@ -286,6 +286,23 @@ def cut_prompt(prompts, idx):
     return [layout[s] for s in idx], wsel, isel
 
 
+def concat_prompts(*parts):
+    """Batch-concatenation of `make_prompt` triples (the inverse of `cut_prompt`): samples of part 0 first, then part 1, ...
+    Words and images stay packed per sample in prompt order, so every sample keeps exactly the tensors it had alone."""
+    layout = [p for part in parts for p in part[0]]
+    words = torch.cat([part[1] for part in parts])
+    imgs0 = parts[0][2]
+    imgs = MapDict({k: MapDict({v: torch.cat([part[2][k][v] for part in parts]) for v in imgs0[k]}) for k in imgs0})
+    return layout, words, imgs
+
+
+def concat_obs(*parts):
+    """Batch-concatenation (dim 1) of `make_obs` dicts."""
+    o0 = parts[0]["objects"]
+    return {"objects": MapDict({k: MapDict({v: torch.cat([p["objects"][k][v] for p in parts], dim=1) for v in o0[k]}) for k in o0}),
+            "ee": torch.cat([p["ee"] for p in parts], dim=1)}
+
+
 def cut_obs(obs, idx):
     """Sub-batch `idx` of a `make_obs` dict (batch is dim 1)."""
     return {"objects": MapDict({k: MapDict({v: obs["objects"][k][v][:, idx] for v in obs["objects"][k]})
