@@ -16,12 +16,12 @@ pol = VIMAPolicy(embed_dim=256, xf_n_layers=1, sattn_n_heads=8, xattn_n_heads=8,
 pol._ensure_handle()
 pol.set_option("op_bf16_out", 1)
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
-for (N, K, act) in ((768, 768, 0), (2304, 768, 0), (3072, 768, 2), (768, 3072, 0)):
+for (N, K, act) in ((768, 768, 0), (1536, 768, 0), (2304, 768, 0), (768, 3072, 0)):
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * 0.03
     out = torch.empty(M, N, device="cuda")
     ref = None
-    for tile in (0, 1, 8, 9, 2):
+    for tile in (0, 1, 8, 13, 14):
         pol.set_option("gemm_tile", tile)
         try:
             for _ in range(3):

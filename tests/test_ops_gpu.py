@@ -217,6 +217,7 @@ def test_small_tiles_match_128_tile_bitwise():
     """The 64x64 / 32x64 tiles chosen for underfilled grids accumulate K in the same order as the 128x128 tile: results
     must be BIT-identical (batch-composition invariance does not depend on the tile choice)."""
     pol = bare_policy("bf16")
+    pol.set_option("gemm_skinny", 0)                  # (M <= 32 otherwise takes gemm_skinny_kernel, whose K split is a different summation order)
     g = torch.Generator().manual_seed(9)
     try:
         for M, N, K in [(8, 768, 3072), (32, 2304, 768), (200, 768, 768), (500, 3072, 768)]:
@@ -232,6 +233,7 @@ def test_small_tiles_match_128_tile_bitwise():
             assert torch.equal(outs[0], outs[1]), (M, N, K)
     finally:
         pol.set_option("gemm_small", 1)
+        pol.set_option("gemm_skinny", 1)
 
 
 def test_resident_kernel_matches_ring_tiles_bitwise():
@@ -241,6 +243,7 @@ def test_resident_kernel_matches_ring_tiles_bitwise():
     (gemm_resident = 0) -- full, ragged and single-slice shapes, K / 64 not a multiple of the chunk, every epilogue the decoder
     uses (bias, GELU, gate, fp32 residual; bf16-only output; bf16 residual stream)."""
     pol = bare_policy("bf16")
+    pol.set_option("gemm_skinny", 0)                  # the launcher's own choice for M <= 32 is gemm_skinny_kernel (test_skinny_kernel_*): not bit-identical by design
     g = torch.Generator().manual_seed(21)
     shapes = [(8, 768, 3072), (9, 768, 768), (32, 2304, 768), (18, 3072, 768), (40, 768, 768), (200, 768, 768), (288, 768, 3072),
               (500, 1536, 768), (33, 100, 192), (5, 36, 64), (64, 96, 320), (300, 200, 448)]
@@ -272,7 +275,61 @@ def test_resident_kernel_matches_ring_tiles_bitwise():
                         d = (outs[name] - outs["ring"]).abs().max().item()
                         assert torch.equal(outs[name], outs["ring"]), (M, N, K, mode, act, ub, um, ur, name, d)
     finally:
-        for k, v in (("gemm_resident", 1), ("gemm_tile", 0), ("gemm_res_nch", 0), ("op_bf16_out", 0), ("op_stream_T", 0)):
+        for k, v in (("gemm_resident", 1), ("gemm_tile", 0), ("gemm_res_nch", 0), ("op_bf16_out", 0), ("op_stream_T", 0), ("gemm_skinny", 1)):
+            pol.set_option(k, v)
+
+
+def test_skinny_kernel_against_fp64_and_the_resident_tile():
+    """Round 5: gemm_skinny_kernel (M <= 32: K split over the 4 / 8 / 16 waves of a workgroup, operands straight from global memory in the MFMA
+    layout, partial accumulators reduced through LDS) -- every epilogue the decoder uses, all three output modes, K from one k-step per wave to
+    192 (three batch sizes of the loop), ragged N, M = 1 .. 32. Not bit-identical to the other tiles (different summation order): compared with
+    the fp64 product of the bf16-rounded operands (the tolerance of test_linear_epilogues) and with the resident 32x32 tile to fp32 rounding
+    (bf16 outputs: at most one bf16 ulp apart); two launches of the same problem agree bit for bit."""
+    pol = bare_policy("bf16")
+    g = torch.Generator().manual_seed(77)
+    shapes = [(9, 768, 768), (8, 768, 3072), (32, 2304, 768), (1, 512, 768), (18, 3072, 768), (5, 36, 64), (32, 100, 192), (17, 256, 1024), (9, 1024, 2048),
+              (3, 64, 4096), (12, 700, 512)]
+    combos = [(0, False, False, False), (0, True, False, True), (2, True, True, False), (2, False, True, True), (1, True, False, False), (3, True, False, True)]
+    worst = 0.0
+    try:
+        for M, N, K in shapes:
+            A, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+            b, mu, r = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+            for mode in ("f32out", "bf16out", "streamT"):
+                pol.set_option("op_bf16_out", 1 if mode == "bf16out" else 0)
+                pol.set_option("op_stream_T", 1 if mode == "streamT" else 0)
+                for act, ub, um, ur in combos:
+                    if mode == "streamT" and (act != 0 or not ur):
+                        continue
+                    outs = {}
+                    for name, sk in (("resident", 0), ("skinny", 1), ("skinny2", 1)):
+                        pol.set_option("gemm_skinny", sk)
+                        out = torch.full((M, N), float("nan"), device="cuda")
+                        pol.prof_enable(True)
+                        _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(A), ptr(W), ptr(b) if ub else None, ptr(mu) if um else None,
+                                                           ptr(r) if ur else None, M, N, K, act, ptr(out), pol._stream()))
+                        torch.cuda.synchronize()
+                        kinds = list(pol.prof_read_gemm_kernels())
+                        pol.prof_enable(False)
+                        assert any("skinny" in k for k in kinds) == bool(sk), (name, kinds)
+                        outs[name] = out
+                    assert torch.equal(outs["skinny"], outs["skinny2"])
+                    ref = bf(A).double() @ bf(W).double().T
+                    if ub:
+                        ref = ref + b.double()
+                    ref = ACTS[act](ref.float())
+                    if um:
+                        ref = ref * bf(mu)
+                    if ur:
+                        ref = ref + (bf(r) if mode == "streamT" else r)
+                    tol = 2e-3 if mode == "f32out" else 1e-2
+                    assert max_rel(outs["skinny"], ref.cuda()) < tol, (M, N, K, mode, act, ub, um, ur, max_rel(outs["skinny"], ref.cuda()))
+                    d = max_rel(outs["skinny"], outs["resident"])
+                    worst = max(worst, d if mode == "f32out" else 0.0)
+                    assert d < (2e-5 if mode == "f32out" else 8e-3), (M, N, K, mode, act, ub, um, ur, d)
+        print(f"[skinny] worst fp32-output deviation from the resident tile over {len(shapes)} shapes: {worst:.2e} (relative to max |out|)")
+    finally:
+        for k, v in (("op_bf16_out", 0), ("op_stream_T", 0), ("gemm_skinny", 1)):
             pol.set_option(k, v)
 
 

@@ -146,7 +146,7 @@ def test_bf16_argmax_agreement_o1_logits_live_oracle():
 
 
 
-@pytest.mark.parametrize("opts", [{"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 2}, {"gemm_wide": 1}, {"gemm_pp": 0}, {"graphs": 1}, {"gemm_resident": 0},
+@pytest.mark.parametrize("opts", [{"gemm_skinny": 0}, {"gemm_small": 0}, {"gemm_persist": 0}, {"gemm_splitk": 1}, {"t5_fuse_rms": 0}, {"stream_T": 0}, {"attn_qg": 2}, {"gemm_wide": 1}, {"gemm_pp": 0}, {"graphs": 1}, {"gemm_resident": 0},
                                   {"dual_stream": 0}, {"attn_split": 0}, {"gemm_epi": 0}, {"vit_prune_last": 0}, {"ln_fuse": 0}])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_every_option_matches_reference_golden(opts, prec, golden_dir):
@@ -167,7 +167,7 @@ def test_every_option_matches_reference_golden(opts, prec, golden_dir):
     finally:
         for k in opts:                                         # (options are per handle; restoring is belt and braces)
             pol.set_option(k, {"gemm_small": 1, "gemm_persist": 1, "gemm_splitk": 0, "t5_fuse_rms": 1, "stream_T": 1, "attn_qg": 1, "gemm_wide": 0, "gemm_pp": 1, "graphs": 0, "dual_stream": 1, "gemm_resident": 1,
-                               "attn_split": 1, "gemm_epi": 1, "vit_prune_last": 1, "ln_fuse": 1}[k])
+                               "attn_split": 1, "gemm_epi": 1, "vit_prune_last": 1, "ln_fuse": 1, "gemm_skinny": 1}[k])
 
 
 def test_stagewise_against_oracle_fp32():
@@ -240,7 +240,7 @@ def test_resident_gemm_kernel_is_exact_in_the_policy(name):
     for res, maxwg in ((0, 256), (1, 256), (1, 4096), (1, 8)):
         # (ln_fuse = 0: the folded LayerNorm of XAttention's feed-forward exists in the resident kernel's pair form only, so switching that kernel
         # off would also switch the fold off -- a different rounding point, tested in test_ln_fuse_*; THIS test is about the kernel's K order)
-        pol = loaded_policy(cfg, sd, "bf16", gemm_resident=res, gemm_res_maxwg=maxwg, ln_fuse=0)
+        pol = loaded_policy(cfg, sd, "bf16", gemm_resident=res, gemm_res_maxwg=maxwg, ln_fuse=0, gemm_skinny=0)
         for _ in range(2):
             o = native_outputs(pol, prompts, obs, actions)
         outs.append(o)
@@ -585,7 +585,17 @@ def test_full_size_200m_headline_batch_against_reference(golden_dir):
     ptok_s, pmask_s = pol.forward_prompt_assembly(syn.to_device(p_sub, DEV))
     otok_s, omask_s = pol.forward_obs_token(syn.to_device(o_sub, DEV))
     logits_s = pol.action_logits(pol.forward(otok_s, omask_s, None, ptok_s, pmask_s)[-1])
-    assert max_abs(logits_s, logits[sub]) < 1e-5, "samples of a batch must be independent"
+    # Round 5: GEMMs of at most 32 rows (this sub-batch's decoder: 4 x 8 rows, its action head) run on gemm_skinny_kernel, whose K split sums in
+    # another order than the tiles of the batch-256 run: equal to bf16 rounding (a fraction of the 1e-3 gate), and bit-level again with the option off
+    d_s = max_abs(logits_s, logits[sub])
+    pol.set_option("gemm_skinny", 0)
+    ptok_x, pmask_x = pol.forward_prompt_assembly(syn.to_device(p_sub, DEV))
+    otok_x, omask_x = pol.forward_obs_token(syn.to_device(o_sub, DEV))
+    logits_x = pol.action_logits(pol.forward(otok_x, omask_x, None, ptok_x, pmask_x)[-1])
+    pol.set_option("gemm_skinny", 1)
+    print(f"[parity] sub-batch of 4 vs its rows of the batch-256 run: {d_s:.3e} (gemm_skinny on) / {max_abs(logits_x, logits[sub]):.3e} (off)")
+    assert d_s < 5e-4, "samples of a batch must be independent"
+    assert max_abs(logits_x, logits[sub]) < 1e-5, "samples of a batch must be independent"
     # north_star's batch 1 at full size: sample sub[0] ALONE (M = 9 decoder rows: the 32x32 resident tiles, the grouped action head and
     # the dual GEGLU launch) against the reference's logits for that sample and against its row of the batch-256 run
     one = [sub[0]]
@@ -596,7 +606,7 @@ def test_full_size_200m_headline_batch_against_reference(golden_dir):
     print(f"[parity] batch 1 (sample {sub[0]} alone) vs reference: max|logit err| {err1:.3e}; vs its row of the batch-256 run: "
           f"{max_abs(logits_1, logits[one]):.3e}")
     assert err1 < 1e-3, err1
-    assert max_abs(logits_1, logits[one]) < 1e-5, "a sample alone must reproduce its row of the full batch"
+    assert max_abs(logits_1, logits[one]) < 5e-4, "a sample alone must reproduce its row of the full batch (to bf16 rounding: gemm_skinny_kernel)"
     # opt-in split-K for underfilled grids: the sub-batch then sums K in a different order than the full batch
     pol.set_option("gemm_splitk", 1)
     ptok_k, pmask_k = pol.forward_prompt_assembly(syn.to_device(p_sub, DEV))

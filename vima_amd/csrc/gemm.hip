@@ -72,6 +72,8 @@ using TileS = Tile<128, 128, 2, 2, 128, 2>;   // 64 KiB, 2 workgroups / CU
 using Tile64 = Tile<64, 64, 2, 2, 128, 4>;    // 64 KiB ring of four 16-KiB slices, 4 waves of 32x32: underfilled grids (M <= 512 or so)
 using TileXS = Tile<32, 64, 1, 2, 128, 4>;    // 48 KiB ring of four 12-KiB slices, 2 waves of 32x32: M <= 32 (one env step at batch <= 4)
 using TileL = Tile<256, 256, 2, 4, 128, 2>;   // 128 KiB, 1 workgroup / CU, 8 waves
+using Tile64x128 = Tile<64, 128, 2, 2, 128, 4>;   // 96 KiB ring of four 24-KiB slices, 4 waves of 32x64 (two independent accumulators per wave)
+using Tile128x64 = Tile<128, 64, 2, 2, 128, 4>;   // the transposed shape: 4 waves of 64x32
 
 template <int RB> __device__ __forceinline__ int swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
@@ -276,6 +278,7 @@ struct GemmDev {
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
   int wide8;    // bf16-only output with 8-column alignment: 16-byte stores in the LDS epilogue
   int res_nch;  // gemm_resident_kernel: chunk buffers in LDS
+  int sk_cols;  // gemm_skinny_kernel: output columns per workgroup (32 / 16 / 8)
   const int* grp_col;   // gemm_resident_kernel, grouped form (GemmArgs::grp_col): column starts of the groups, or nullptr
   const void* A2; const void* W2; int lda2, ldw2;   // gemm_resident_kernel<RTile<.., DUAL>>: the gate product's operands
   long long* dbg;   // optional: 8 debug slots per workgroup (shader-clock stamps of the 4 phases, real time, placement)
@@ -1833,6 +1836,7 @@ __global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const Gemm
 
 #ifndef VIMA_GEMM_LAB
 #include "gemm_small.inc"   // gemm_resident_kernel: underfilled grids (batch 1 .. 32, one env step), whole K in flight
+#include "gemm_skinny.inc"  // gemm_skinny_kernel: M <= 32 (one env step at batch <= 3), K split over the waves of a workgroup, operands straight from global memory
 #endif
 
 // Knob resolution: the handle's Tuning value when set (>= 0), otherwise the process default from the environment
@@ -1864,6 +1868,8 @@ VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
 VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
 int g_env_res_nch = -1;
 VIMA_KNOB(gemm_res_nch, gemm_res_nch, "VIMA_GEMM_RES_NCH", g_env_res_nch, 0)
+int g_env_skinny = -1;
+VIMA_KNOB(gemm_skinny, gemm_skinny, "VIMA_GEMM_SKINNY", g_env_skinny, 1)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -2182,6 +2188,60 @@ int launch_resident(const GemmDev& d, const GemmArgs& a, int force, hipStream_t 
 #endif
 
 
+// ------------------------------------------------------------------------------------------------ skinny (M <= 32)
+#ifndef VIMA_GEMM_LAB
+template <typename ST, int ACT>
+int launch_skinny_inst(const GemmDev& d, dim3 grid, hipStream_t st) {
+  static PerDeviceOnce attr;   // per instantiation, per device
+  if (ST::SMEM > 48 * 1024) {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<ST, ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ST::SMEM); });
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL((gemm_skinny_kernel<ST, ACT>), grid, dim3(ST::THREADS), (size_t)ST::SMEM, st, d);
+  return (int)hipGetLastError();
+}
+template <typename ST>
+int launch_skinny_act(const GemmDev& d, const GemmArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.act) {
+    case ACT_NONE: return launch_skinny_inst<ST, ACT_NONE>(d, grid, st);
+    case ACT_RELU: return launch_skinny_inst<ST, ACT_RELU>(d, grid, st);
+    case ACT_GELU: return launch_skinny_inst<ST, ACT_GELU>(d, grid, st);
+    case ACT_QUICKGELU: return launch_skinny_inst<ST, ACT_QUICKGELU>(d, grid, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+// bf16 problems of at most 32 rows with a vector-aligned epilogue and no fp8 operands; < 0 = not taken. The number of waves (= the K split)
+// depends on K only.
+int launch_skinny(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (a.M > 32 || a.w8 || a.a8 || a.out8 || a.K % 64 != 0 || a.N % 4 != 0 || a.grp_col || a.hm_D || a.pair32) return -1;
+  if ((a.ssq_out || a.resT) && a.act != ACT_NONE) return -1;
+  if (a.W2 && (a.act != ACT_GELU || a.K > 2048)) return -1;
+  if ((long long)a.M * a.lda * 2 >= (1LL << 31) || (long long)a.N * a.ldw * 2 >= (1LL << 31)) return -1;   // buffer descriptors with 31-bit byte ranges
+  if (a.W2 && ((long long)a.M * a.lda2 * 2 >= (1LL << 31) || (long long)a.N * a.ldw2 * 2 >= (1LL << 31))) return -1;
+  // columns per workgroup: the narrowest of 32 / 16 / 8 that still leaves whole tiles and at most ~256 workgroups -- what bounds a launch is the
+  // bytes ONE workgroup pulls (a CU streams ~24 GB/s), so N is spread over as many CUs as there are; partial sums for a downstream fused norm are
+  // per 32 columns and need the full-width tile
+  const long long nb = a.batch > 0 ? a.batch : 1;
+  int cols = 32;
+  static int force_cols = -1;
+  if (force_cols < 0) force_cols = env_int("VIMA_SKINNY_COLS", 0);
+  if (!a.ssq_out) {
+    while (cols > 8 && a.N % (cols / 2) == 0 && (long long)(a.N / (cols / 2)) * nb <= 400) cols /= 2;
+    if (force_cols == 8 || force_cols == 16 || force_cols == 32) cols = force_cols;
+  }
+  d.sk_cols = cols;
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
+  const dim3 grid((unsigned)((a.N + cols - 1) / cols), (unsigned)nb, 1);
+  const int ks = a.K / 16;
+  if (a.kernel_id) *a.kernel_id = (a.W2 ? 18 : 17) * 1000 + (a.act + 1) * 10;
+  if (a.W2) return ks <= 64 ? launch_skinny_inst<SkTile<4, 12, true>, ACT_GELU>(d, grid, st) : launch_skinny_inst<SkTile<8, 8, true>, ACT_GELU>(d, grid, st);
+  if (ks <= 64) return launch_skinny_act<SkTile<4, 12, false>>(d, a, grid, st);
+  if (ks <= 128) return launch_skinny_act<SkTile<8, 12, false>>(d, a, grid, st);
+  return launch_skinny_act<SkTile<16, 12, false>>(d, a, grid, st);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ split-K
 // With M = 8 .. 512 rows (batch 1 .. 32 decoder / prompt GEMMs) a 128x128 grid has 6 .. 100 workgroups, each walking
 // its K dimension serially at the per-CU operand-path rate (~23 B/clk): 8 us at K = 768, 30 us at K = 3072, most CUs
@@ -2321,6 +2381,10 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (a.grp_col || a.W2) {
       if (a.W2 && !v) return (int)hipErrorInvalidValue;
+      if (a.W2 && a.M <= 32 && gemm_skinny(a.tune)) {
+        const int e = launch_skinny(d, a, st);
+        if (e >= 0) return e;
+      }
       const int e = launch_resident(d, a, 0, st);
       return e >= 0 ? e : (int)hipErrorInvalidValue;
     }
@@ -2381,6 +2445,10 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     {   // the same class with (almost) the whole K extent in flight (gemm_small.inc); bit-identical to the ring tiles
       const int gt = gemm_tile(a.tune);
       const int force = (gt >= 10 && gt <= 12) ? gt : 0;
+      if (v && gt == 0 && a.M <= 32 && gemm_small(a.tune) && gemm_resident(a.tune) && gemm_skinny(a.tune)) {   // at most 32 rows: K split over the waves
+        const int e = launch_skinny(d, a, st);
+        if (e >= 0) return e;
+      }
       if (v && (force || (gt == 0 && gemm_small(a.tune) && gemm_resident(a.tune) && t128 < 128))) {
         const int e = launch_resident(d, a, force, st);
         if (e >= 0) return e;
@@ -2391,6 +2459,8 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       if (a.M <= 32) return launch_tile<T, TileXS, true>(d, a, v, st);
       return launch_tile<T, Tile64, true>(d, a, v, st);
     }
+    if (gemm_tile(a.tune) == 13 && v) return launch_tile<T, Tile64x128, true>(d, a, v, st);
+    if (gemm_tile(a.tune) == 14 && v) return launch_tile<T, Tile128x64, true>(d, a, v, st);
     if (gemm_tile(a.tune) == 7 && v) return launch_tile<T, TileXS, true>(d, a, v, st);
     if (gemm_tile(a.tune) == 8 && v) return launch_tile<T, Tile64, true>(d, a, v, st);
   }

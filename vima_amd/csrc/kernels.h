@@ -19,6 +19,7 @@ struct Tuning {
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
   int gemm_resident = -1;  // VIMA_GEMM_RESIDENT 1 = underfilled grids on gemm_resident_kernel (whole K in flight; default), 0 = the 4-deep ring tiles
   int gemm_res_maxwg = -1; // VIMA_GEMM_RES_MAXWG largest grid (workgroups) that kernel takes at M > 32 (default 256 = one per CU)
+  int gemm_skinny = -1;    // VIMA_GEMM_SKINNY   1 = GEMMs of at most 32 rows on gemm_skinny_kernel (K split over the waves of a workgroup; default), 0 = the resident 32x32 tile (bit-identical to every other tile)
   int gemm_res_nch = -1;   // VIMA_GEMM_RES_NCH  chunk buffers of that kernel's LDS ring (0 = default: 4 / 5 / 4 = up to 128 KiB; max 5 / 6 / 5 = 160 KiB)
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel
@@ -98,7 +99,8 @@ struct GemmArgs {
   const Tuning* tune = nullptr;   // the calling handle's knobs (nullptr: process defaults)
   // out (profiling): which kernel the launcher chose = kind * 1000 + (act + 1) * 10 + epi ; kind 1 gemm_pp_kernel,
   // 2 gemm_persistent_kernel, 3 gemm_wide_kernel, 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile (epi 0),
-  // 8 two-pass split-K, 10 / 11 / 12 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 tile, 15 / 16 its DUAL (GEGLU pair) form on the 32x32 / 64x64 tile
+  // 8 two-pass split-K, 10 / 11 / 12 gemm_resident_kernel with the 32x32 / 64x32 / 64x64 tile, 15 / 16 its DUAL (GEGLU pair) form on the 32x32 / 64x64 tile,
+  // 17 / 18 gemm_skinny_kernel (M <= 32) / its DUAL form
   int* kernel_id = nullptr;
   // fp8 weights (precision "fp8w", bf16 activations): W is [N,K] OCP e4m3 BYTES (ldw / bsW in elements = bytes) and
   // wscale[n] the per-output-channel dequantisation scale; the kernel widens the fragments to bf16 in registers and

@@ -535,7 +535,8 @@ class VIMAPolicy(nn.Module):
                    7: "vima::gemm_kernel<Tile<32, 64>>", 8: "vima::gemm_kernel (two-pass split-K)", 9: "vima::gemm_pp_kernel",
                    10: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 4>>", 11: "vima::gemm_resident_kernel<RTile<64, 32, 2, 1, 2>>",
                    12: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>>", 15: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 2, true>> (GEGLU pair)",
-                   16: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 1, true>> (GEGLU pair)"}
+                   16: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 1, true>> (GEGLU pair)",
+                   17: "vima::gemm_skinny_kernel", 18: "vima::gemm_skinny_kernel (GEGLU pair)"}
 
     def _gemm_kernel_name(self, kid: int) -> str:
         kind, rest = divmod(int(kid), 1000)
