@@ -265,6 +265,7 @@ struct GemmDev {
   float* out32; int ld32;
   void* outT; int ldT;
   int rb, s_hi, s_lo, ro;
+  void* outT_lo; int ldT_lo, split_n;   // GemmArgs::split_n: columns < split_n go to outT_lo[m][n] (no row remap), the others to outT[orow][n - split_n]
   int hm_D, hm_L;   // head-major output of the 256x256 bf16-output epilogue (GemmArgs::hm_D / hm_L; 0 = row-major)
   float* ssq_out; const float* rs_ssq; int rs_parts; float rs_invk, rs_eps;
   float* sum_out; const float* rs_sum; const float* rs_c;   // fused LayerNorm (GemmArgs::sum_out / rs_sum / rs_c)
@@ -631,6 +632,10 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
                 }
                 uint4 o;
                 o.x = pack2_bf16(v0.x, v0.y); o.y = pack2_bf16(v0.z, v0.w); o.z = pack2_bf16(v1.x, v1.y); o.w = pack2_bf16(v1.z, v1.w);
+                if (p.split_n) {
+                  if (n8 < p.split_n) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.outT_lo) + (long long)m * p.ldT_lo + n8) = o;
+                  else *reinterpret_cast<uint4*>(outT + orow * p.ldT + (n8 - p.split_n)) = o;
+                } else
                 *reinterpret_cast<uint4*>(outT + orow * p.ldT + n8) = o;
                 if (kStreamEpi) sq8 = sumsq8_bf16(o);
               }
@@ -655,7 +660,12 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
             if (res) { const float4 r4 = load4(res + (long long)m * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
             if (resT) { const float4 r4 = load4(resT + (long long)m * p.ldresT + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
             if (out32) store4(out32 + orow * p.ld32 + n, v);
-            if (outT) store4(outT + orow * p.ldT + n, v);
+            if (outT) {
+              if (p.split_n) {
+                if (n < p.split_n) store4(reinterpret_cast<T*>(p.outT_lo) + (long long)m * p.ldT_lo + n, v);
+                else store4(outT + orow * p.ldT + (n - p.split_n), v);
+              } else store4(outT + orow * p.ldT + n, v);
+            }
             sq = sumsq4(v);
             sm = (v.x + v.y) + (v.z + v.w);
           }
@@ -706,7 +716,12 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
           if (resT) { const float4 r4 = load4(resT + (long long)m * p.ldresT + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
           const float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (out32) store4(out32 + orow * p.ld32 + n, o);
-          if (outT) store4(outT + orow * p.ldT + n, o);
+          if (outT) {
+            if (p.split_n) {
+              if (n < p.split_n) store4(reinterpret_cast<T*>(p.outT_lo) + (long long)m * p.ldT_lo + n, o);
+              else store4(outT + orow * p.ldT + (n - p.split_n), o);
+            } else store4(outT + orow * p.ldT + n, o);
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -2346,6 +2361,11 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.out32 = a.out32; d.ld32 = a.ld32; d.outT = a.outT; d.ldT = a.ldT;
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.hm_D = a.hm_D; d.hm_L = a.hm_L;
+  d.outT_lo = a.outT_lo; d.ldT_lo = a.ldT_lo; d.split_n = a.split_n;
+  if (a.split_n && (sizeof(T) != 2 || !a.outT || !a.outT_lo || a.out32 || a.out8 || a.mul || a.res || a.resT || a.ssq_out || a.hm_D || a.pair32 || a.W2 || a.grp_col ||
+                    a.batch > 1 || a.split_n <= 0 || a.split_n >= a.N || a.split_n % 128 != 0 || a.N % 8 != 0 || a.ldT_lo % 8 != 0 || !aligned_to(a.outT_lo, 16) ||
+                    a.w8 || a.a8 || gemm_splitk(a.tune)))
+    return (int)hipErrorInvalidValue;
   if (a.hm_D && (sizeof(T) != 2 || !a.outT || a.out32 || a.mul || a.res || a.resT || a.out8 || a.ssq_out || a.rb > 0 || a.batch > 1 || a.grp_col || a.W2 ||
                  !gemm_headmajor_ok(a.tune, a.M, a.N, a.K, a.lda, a.ldw, a.hm_D, a.hm_L, a.a8)))
     return (int)hipErrorInvalidValue;
@@ -2409,7 +2429,7 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 160) && waste < 1.15;   // measured: 192 tiles of 256x256 beat 768 of 128x128 by 10-28 %
-    if (gemm_tile(a.tune) == 1) large = false;
+    if (gemm_tile(a.tune) == 1 || a.split_n) large = false;   // (the column-split output exists in the one-tile-per-workgroup / resident / skinny epilogues)
     if (gemm_tile(a.tune) >= 2 && gemm_tile(a.tune) < 7) large = v;
     if (gemm_tile(a.tune) >= 7) large = false;
     if (large && gemm_wide(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {

@@ -72,6 +72,11 @@ struct GemmArgs {
   int pair32 = 0;
   // output-row remap (outputs only): orow = (r / rb) * s_hi + (r % rb) * s_lo + ro ; rb == 0 -> identity
   int rb = 0, s_hi = 0, s_lo = 0, ro = 0;
+  // COLUMN-SPLIT output (bf16, outT only, no residual / gate / statistics; split_n % 128 == 0): columns n < split_n are stored to outT_lo[r * ldT_lo + n]
+  // (rows NOT remapped), columns n >= split_n to outT[orow * ldT + (n - split_n)]. One launch for the self-attention projection of an incremental
+  // decoding step: q of the new tokens to a dense buffer, their k | v rows appended to the episode cache through the row remap (components.py:51-58).
+  void* outT_lo = nullptr;
+  int ldT_lo = 0, split_n = 0;
   // RMS statistics fused into the GEMMs either side of a T5 RMSNorm (the norm's weight is folded into W at pack time):
   //   producer: ssq_out[r][j] = sum over columns [32j, 32j+32) of out[r][n]^2 (final fp32 values; needs out32, N % 32 == 0,
   //             batch 1). Plain stores of N/32 partials per row -- no atomics, so the result is deterministic and the

@@ -2104,6 +2104,13 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
       // q of the new tokens; their k / v rows are APPENDED to the layer's episode cache by the GEMM's row-remap epilogue
       // (row b*Lq + i -> b*Lmax + L_hist + i); the new queries attend to history + themselves with a causal offset
       void* cache = reinterpret_cast<char*>(h->ep_kv) + (size_t)i * B * Lmax * 2 * E * h->esz();
+      if (h->bf16 && !D.c_attn.ws && E % 128 == 0 && !gemm_splitk_enabled(&h->tune)) {   // one launch: q columns dense, k | v columns appended to the cache
+        GemmArgs gq;
+        gq.A = xT; gq.lda = E; R.setW(gq, D.c_attn, 0); gq.M = rq; gq.N = 3 * E; gq.K = E; gq.bias = D.c_attn.b;
+        gq.outT_lo = qkv; gq.ldT_lo = E; gq.split_n = E;
+        gq.outT = cache; gq.ldT = 2 * E; gq.rb = Lq; gq.s_hi = Lmax; gq.s_lo = 1; gq.ro = L_hist;
+        R.gemm(gq);
+      } else {
       GemmArgs gq;
       gq.A = xT; gq.lda = E; R.setW(gq, D.c_attn, 0); gq.M = rq; gq.N = E; gq.K = E; gq.bias = D.c_attn.b;
       gq.outT = qkv; gq.ldT = E;
@@ -2113,6 +2120,7 @@ static int decode_launch(VimaHandle* h, const float* obs_tok, const uint8_t* obs
       gk.bias = D.c_attn.b ? D.c_attn.b + E : nullptr;
       gk.outT = cache; gk.ldT = 2 * E; gk.rb = Lq; gk.s_hi = Lmax; gk.s_lo = 1; gk.ro = L_hist;
       R.gemm(gk);
+      }
       s.q = qkv; s.ldq = E; s.k = cache; s.ldk = 2 * E; s.v = R.offT(cache, E); s.ldv = 2 * E;
       s.kmask = h->ep_mask; s.Lk = L_hist + Lq; s.Lk_rows = Lmax; s.q_off = L_hist;
     } else {
