@@ -162,6 +162,62 @@ def live_pmc_traffic(argv_tail, timeout_s=150.0):
     return summ, None
 
 
+def cached_state_dict(syn, cfg, rank, world, dist):
+    """Seeded random weights. One rank: built here. N ranks: rank 0 builds them and writes ONE file, the others wait at a barrier and read it
+    (memory-mapped), rank 0 removes it -- instead of N concurrent host-side builds. Returns (state dict, how it was obtained)."""
+    if world == 1:
+        return syn.make_state_dict(cfg, 0), "built in process"
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"vima_sd_{cfg.embed_dim}_{cfg.xf_n_layers}_{cfg.xattn_n_positions}_{os.environ.get('MASTER_PORT', '0')}.pt")
+    sd = None
+    t0 = time.perf_counter()
+    if rank == 0:
+        sd = syn.make_state_dict(cfg, 0)
+        torch.save(sd, path + ".tmp")
+        os.replace(path + ".tmp", path)
+    dist.barrier()
+    if rank != 0:
+        try:
+            sd = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
+        except TypeError:       # torch without the mmap argument
+            sd = torch.load(path, map_location="cpu")
+    dist.barrier()
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return sd, f"rank 0 built it once ({time.perf_counter() - t0:.1f} s incl. the file), ranks 1..{world - 1} read {os.path.basename(path)}"
+
+
+def rccl_summary(path, max_chars=1500):
+    """What RCCL logged about the communicators of this process (NCCL_DEBUG=INFO, subsystems INIT,GRAPH, into NCCL_DEBUG_FILE): version line,
+    channel count, the first ring / tree lines. Best effort: None when the file is missing or empty."""
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except OSError:
+        return None
+    import re
+    pick = {"version": None, "rings": [], "trees": [], "channels": None, "algo_lines": []}
+    for ln in lines:
+        low = ln.lower()
+        if pick["version"] is None and ("rccl version" in low or "nccl version" in low):
+            pick["version"] = ln.split("INFO", 1)[-1].strip()[:160]
+        if re.search(r"\bring \d+ *:", low) and len(pick["rings"]) < 2:
+            pick["rings"].append(ln.split("INFO", 1)[-1].strip()[:160])
+        if re.search(r"\btrees? \[", low) and len(pick["trees"]) < 1:
+            pick["trees"].append(ln.split("INFO", 1)[-1].strip()[:160])
+        m = re.search(r"(\d+) coll channels", low)
+        if m:
+            pick["channels"] = ln.split("INFO", 1)[-1].strip()[:160]
+    try:
+        pick["torch_nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:   # noqa: BLE001
+        pass
+    pick["log_lines"] = len(lines)
+    out = {k: v for k, v in pick.items() if v}
+    return out or None
+
+
 def usable_cores() -> int:
     """Cores this process may actually use (affinity mask and cgroup CPU quota), not the host's os.cpu_count()."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -179,6 +235,15 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
     workload. Thread count is calibrated first (a 256-thread host with a small cgroup quota is slower at 256 threads)."""
     from oracle.vima_oracle import OraclePolicy
     from vima_testing import synthetic as syn
+    # kind "reference": the UNMODIFIED reference policy (vima/policy/vima_policy.py through oracle/ref_shim.py) when /root/reference exists on this
+    # machine (the build container); on the GPU box it does not, and the timed CPU path is the oracle port (kind "port")
+    ref_mod = None
+    try:
+        from oracle import ref_shim
+        if ref_shim.reference_available():
+            ref_mod = ref_shim
+    except Exception:   # noqa: BLE001
+        ref_mod = None
     ncores = usable_cores()
     cands = sorted({max(1, ncores >> s) for s in range(0, 6)} | {min(ncores, 8)}, reverse=True)
     a = torch.randn(1024, 768)
@@ -196,7 +261,20 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
         if rate > best_rate * 1.05:
             best_t, best_rate = t, rate
     torch.set_num_threads(best_t)
-    orc = OraclePolicy(sd, **cfg.ctor_kwargs())
+    if ref_mod is not None:
+        from oracle.cases import run_policy
+        from oracle.vima_oracle import ACTION_KEYS
+        ref = ref_mod.build_reference_policy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions)
+        ref.load_state_dict(sd, strict=True)
+        ref.eval()
+
+        class _RefCold:   # the reference driven like scripts/example.py drives it: prompt, obs tokens, forward, action decoder
+            def cold_step(self, p, o):
+                _, d = run_policy(ref, p, {"objects": ref_mod.MapDict(o["objects"]), "ee": o["ee"]}, None)
+                return torch.cat([d[k].raw_logits if hasattr(d[k], "raw_logits") else torch.cat([c.logits for c in d[k]._dists], dim=-1) for k in ACTION_KEYS], dim=-1)
+        orc = _RefCold()
+    else:
+        orc = OraclePolicy(sd, **cfg.ctor_kwargs())
     t_start = time.perf_counter()
     with torch.no_grad():
         p1 = syn.make_prompt(1, n_segments=n_seg, words_per_segment=words, q_per_view=qv, seed=1236)
@@ -216,13 +294,16 @@ def run_cpu_baseline(cfg, sd, n_seg, qv, cpu_batch, B, budget_s=30.0, words=8):
                     break
             cb, cdt = cpu_batch, (time.perf_counter() - t1) / max(it, 1)
     samples_per_s = cb / cdt
-    return {"value": round(samples_per_s / B, 6), "unit": "steps/s", "cores": best_t, "kind": "port",
-            "sample": f"oracle (torch fp32 restatement of the reference's CPU path), same VIMA-200M cold workload at batch {cb} "
-                      f"({it} timed pass(es), {cdt:.2f} s each = {samples_per_s:.3f} samples/s), expressed in batch-{B} steps/s. "
-                      "NOT in the timed port: the reference's O(B*Lp) Python prompt-assembly loop (vima_policy.py:168-233; the "
-                      "oracle assembles with index ops) and its DataDict plumbing. /root/reference does not exist on the GPU box, so "
-                      "the shimmed reference cannot be timed there; in the build container (8 cores, batch 4, same workload) the "
-                      "unmodified reference and this port run within 15 % of each other (4.2 vs 4.1 samples/s, profiles/r02_cpu_reference_vs_port.json)",
+    if ref_mod is not None:
+        what = (f"the UNMODIFIED reference policy (/root/reference through oracle/ref_shim.py: prompt assembly incl. its Python loop, obs tokens, forward, "
+                f"action decoder), same VIMA-200M cold workload at batch {cb}")
+    else:
+        what = (f"oracle (torch fp32 restatement of the reference's CPU path), same VIMA-200M cold workload at batch {cb}; NOT in the timed port: the "
+                "reference's O(B*Lp) Python prompt-assembly loop (vima_policy.py:168-233; the oracle assembles with index ops) and its DataDict plumbing. "
+                "/root/reference does not exist on this machine, so the shimmed reference cannot be timed here; in the build container (same workload, batch 4) "
+                "the unmodified reference and this port run within a few per cent of each other (profiles/r05_cpu_reference_vs_port.json)")
+    return {"value": round(samples_per_s / B, 6), "unit": "steps/s", "cores": best_t, "kind": "reference" if ref_mod is not None else "port",
+            "sample": f"{what} ({it} timed pass(es), {cdt:.2f} s each = {samples_per_s:.3f} samples/s), expressed in batch-{B} steps/s",
             "usable_cores": ncores, "host_cpu_count": os.cpu_count(), "threads_tried": cands}
 
 
@@ -407,6 +488,10 @@ def main():
                     "profiles/r*_pmc_traffic.json. The JSON line says which (roofline.traffic_source)")
     ap.add_argument("--launch-log", default=None, help="write the GEMM launch log of one step (kernel, M, N, K in launch order) to this JSON file "
                     "(scripts/pmc_summary.py joins it with per-dispatch counter values)")
+    ap.add_argument("--dry-ranks", type=int, default=0, help="CPU self-check of the N > 1 HOST path (VERDICT r4 item 6): re-launches this script with N ranks "
+                    "over gloo, a stub communicator behind LogitsComm (same call order as the RCCL one: id drawn by rank 0, broadcast, join, all-gather, "
+                    "destroy), the rank-0-written state-dict cache, the agreement all-reduce, K synthetic steps with the barrier / max-over-ranks timing "
+                    "and teardown. No GPU, no policy, no measurement: the line it prints is marked dry_run")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the other BASELINE.json configurations (VIMA-20M batch 32, Lp = 1024 in bf16 "
                     "and fp8, T = 8) that the default run reports under config.secondary_cold")
     args = ap.parse_args()
@@ -416,6 +501,18 @@ def main():
     # VIMA_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the ranks talk over gloo, so that the self-relaunch / rank
     # agreement / max-over-ranks path below can be EXECUTED on a one-GPU box; the printed line is marked and is not a measurement
     shared_gpu = os.environ.get("VIMA_BENCH_SHARED_GPU") == "1"
+    dry = os.environ.get("VIMA_BENCH_DRY") == "1"
+    if args.dry_ranks and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        argv = [a for i, a in enumerate(sys.argv[1:]) if a != "--gpus" and (i == 0 or sys.argv[i] != "--gpus") and not a.startswith("--gpus=")]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.dry_ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + argv + ["--gpus", str(args.dry_ranks)]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, VIMA_BENCH_DRY="1", OMP_NUM_THREADS="1")))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         visible = torch.cuda.device_count()
         if visible < args.gpus and not shared_gpu:
@@ -437,20 +534,30 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if shared_gpu:
         local_rank = 0
-    if torch.cuda.device_count() <= local_rank:
+    if not dry and torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    if not dry:
+        torch.cuda.set_device(dev)
     affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-    host_affinity = pin_to_gpu_numa(local_rank) if world > 1 else {"pinned": False, "reason": "single rank: not pinned"}
+    host_affinity = (pin_to_gpu_numa(local_rank) if world > 1 and not dry else
+                     {"pinned": False, "reason": "dry run: no GPU" if dry else "single rank: not pinned"})
     comm = None
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if shared_gpu:
+        if shared_gpu or dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            # RCCL's own account of what it built (version, channels, ring / tree per channel) goes to a per-process FILE -- stdout carries exactly
+            # one JSON line -- and rank 0's copy is summarised into config.collective_info after the first collectives
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+                os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/vima_rccl_%h_%p.log")
+            rccl_log = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", __import__("socket").gethostname()).replace("%p", str(os.getpid())) or None
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()                  # the LIVE RCCL world size is what gets reported as n_gpus
 
@@ -458,7 +565,15 @@ def main():
     from vima_testing import synthetic as syn
     from vima_amd.policy import VIMAPolicy
     collective = None
-    if world > 1 and shared_gpu:
+    stub = None
+    if world > 1 and dry:
+        stub = parallel.StubCommBackend()
+        comm = parallel.LogitsComm(dev, backend=stub)        # same creation order as the RCCL communicator below: rank 0 draws the id, broadcast, join
+        ok = torch.tensor([1 if comm.world == world else 0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # the agreement step of the real path
+        assert int(ok.item()) == 1
+        collective = "LogitsComm over a StubCommBackend (gloo): DRY RUN of the N > 1 host path, no GPU"
+    elif world > 1 and shared_gpu:
         collective = "torch.distributed all_gather over gloo (VIMA_BENCH_SHARED_GPU test mode: ranks share one GPU, RCCL refuses that)"
     elif world > 1:
         # RCCL communicator behind the C ABI (vima_allgather_logits). Every rank must take the same path: agree on success
@@ -484,33 +599,52 @@ def main():
     seg_len = args.words + Q                         # words + 1 image (Q object tokens) per segment
     assert args.prompt_len % seg_len == 0, "prompt length must be a multiple of words + Q"
     n_seg = args.prompt_len // seg_len
-    cfg = syn.config(args.model, xattn_n_positions=max(256, args.prompt_len))
-    sd = syn.make_state_dict(cfg, 0)                 # seeded random weights (no checkpoints offline)
-    pol = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision=args.precision, device=dev)
-    pol.load_state_dict(sd, strict=True)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        pol.set_option(k, int(v))
+    cfg = syn.config("2M" if dry else args.model, xattn_n_positions=max(256, args.prompt_len))
+    # seeded random weights (no checkpoints offline). N > 1: rank 0 builds them once and the others read its file -- eight concurrent builds of the
+    # 389 M-parameter dict (orthogonal inits on the host) would each take minutes on a node whose cores are split eight ways
+    sd, sd_source = cached_state_dict(syn, cfg, rank, world, dist)
     B = args.batch
-    prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=args.words, q_per_view=args.qv, seed=1236 + rank), dev)
     T = args.steps_history
-    obs = syn.to_device(syn.make_obs(T, B, args.qv, seed=1336 + rank), dev)
-    past = syn.to_device(syn.make_actions(T - 1, B, seed=1436 + rank), dev) if T > 1 else None
+    pol = prompts = obs = past = None
+    if not dry:
+        pol = VIMAPolicy(**cfg.ctor_kwargs(), xattn_n_positions=cfg.xattn_n_positions, precision=args.precision, device=dev)
+        pol.load_state_dict(sd, strict=True)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            pol.set_option(k, int(v))
+        prompts = syn.to_device(syn.make_prompt(B, n_segments=n_seg, words_per_segment=args.words, q_per_view=args.qv, seed=1236 + rank), dev)
+        obs = syn.to_device(syn.make_obs(T, B, args.qv, seed=1336 + rank), dev)
+        past = syn.to_device(syn.make_actions(T - 1, B, seed=1436 + rank), dev) if T > 1 else None
 
     ag_events = []    # (start, end) events around the logits all-gather of every TIMED step (N > 1): a bad scaling curve must be
                       # attributable to the collective or to the ranks' own step time from the JSON line alone
 
-    def step(timed=False):
+    class _HostEvent:      # dry run: the all-gather bracket with the host clock (same (start, end).elapsed_time interface, milliseconds)
+        def __init__(self):
+            self.t = 0.0
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    def local_logits():
+        if dry:            # a value only THIS rank and row can produce: the gathered matrix is checked below
+            return (torch.arange(B, dtype=torch.float32)[:, None] + 1000.0 * rank).expand(B, 700).contiguous()
         ptok, pmask = pol.forward_prompt_assembly(prompts)
         otok, omask = pol.forward_obs_token(obs)
         atok = pol.forward_action_token(past) if past is not None else None
         pred = pol.forward(otok, omask, atok, ptok, pmask)
-        logits = pol.action_logits(pred[-1])
+        return pol.action_logits(pred[-1])
+
+    def step(timed=False):
+        logits = local_logits()
         if world == 1:
             return logits
         if not timed:
             return parallel.all_gather_logits(logits, global_batch=B * world, comm=comm)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = (_HostEvent(), _HostEvent()) if dry else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         e0.record()        # torch's current stream = the stream LogitsComm enqueues vima_allgather_logits on
         out_ = parallel.all_gather_logits(logits, global_batch=B * world, comm=comm)
         e1.record()
@@ -518,10 +652,12 @@ def main():
         return out_
 
     def sync():
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if not dry:
+                torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         out = step()
@@ -529,14 +665,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(timed=True)
-    torch.cuda.synchronize(dev)
+    if not dry:
+        torch.cuda.synchronize(dev)
     dt_own = time.perf_counter() - t0          # this rank's own K steps, before the closing barrier
     sync()
     dt = time.perf_counter() - t0
     ranks_info = None
     if world > 1:
         ag_us = sum(a.elapsed_time(b) for a, b in ag_events) / max(len(ag_events), 1) * 1e3
-        mine = torch.tensor([dt, dt_own, ag_us], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt, dt_own, ag_us], dtype=torch.float64, device=dev)   # (gloo gathers host tensors in the dry run)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu()
@@ -550,6 +687,27 @@ def main():
                               "logits all-gather on its stream, mean over the timed steps (includes waiting for the slowest rank to arrive)"}
     assert out.shape == (B * world, 700) and bool(torch.isfinite(out).all())
     ms_per_step = dt / args.steps * 1e3
+    collective_info = None
+    if rccl_log and rank == 0:
+        collective_info = rccl_summary(rccl_log)
+    if dry:
+        # every rank holds every rank's rows, in rank order
+        want = (torch.arange(B, dtype=torch.float32)[None, :] + 1000.0 * torch.arange(world, dtype=torch.float32)[:, None]).reshape(-1)
+        assert torch.equal(out[:, 0], want) and torch.equal(out[:, 699], want), "dry run: the gathered logits are not [rank 0 rows, rank 1 rows, ...]"
+        calls = [None] * world
+        dist.all_gather_object(calls, stub.calls)
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            assert all(c[:1] == ["create"] for c in calls[1:]) and calls[0][:2] == ["unique_id", "create"], calls
+            assert all(c.count("all_gather") == args.steps + args.warmup for c in calls), calls
+            print(json.dumps({"metric": "policy-forward steps/sec, VIMA-200M, 512-token prompt, batch 256", "value": None, "unit": "steps/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "dry_run": True, "data": "synthetic",
+                              "config": {"workload": "DRY RUN of bench.py's N > 1 host path on CPU: no GPU, no policy; NOT a measurement",
+                                         "global_batch": B * world, "parallelism": f"dp{world}", "collective": collective, "state_dict": sd_source,
+                                         "stub_calls_rank0": calls[0][:3] + ["..."] + calls[0][-1:], "ranks": ranks_info, "host_affinity": [host_affinity]}}))
+        return
 
     warm_ms = inc_ms = float("nan")
     secondary = {}
@@ -637,7 +795,8 @@ def main():
                 "durations, what rocprofv3 --kernel-trace reports for the committed profile); achieved = ALGORITHMIC flops or bytes "
                 "(each operand / output / epilogue input once) over that time; `bound` from the kernel's flop/byte vs the 312 FLOP/B "
                 "machine balance; `kernel` = the kernel with the most time in the step; `traffic` = ITS HBM bytes per launch from the "
-                "committed rocprofv3 PMC passes (`traffic_all_gemm_launches`: average over all bf16 GEMM launches). "
+                + ("rocprofv3 PMC passes collected live by this run" if _LIVE_PMC is not None else "committed rocprofv3 PMC passes (profiles/)")
+                + " (`traffic_source`; `traffic_all_gemm_launches`: average over all bf16 GEMM launches). "
                 "whole_step_*: the 49.09 TFLOP algorithmic numerator over the timed wall clock (the last ViT block is computed for the "
                 "cls token only -- executed GEMM FLOPs are ~6 % below the algorithmic count)",
     })
@@ -679,6 +838,7 @@ def main():
             "config": {"workload": f"VIMA-{args.model} COLD policy forward (prompt assembly ViT+T5, obs ViT, XAttnGPT, action head) "
                                    f"batch {B}/GPU, {args.prompt_len}-token prompt ({n_seg} x [{args.words} words + 1 image]), {Q} object tokens/obs, T={T}",
                        "global_batch": B * world, "prompt_len": args.prompt_len, "parallelism": f"dp{world}", "collective": collective,
+                       "collective_info": collective_info, "state_dict": sd_source,
                        "samples_per_s": round(world * B * args.steps / dt, 1),
                        "algorithmic_tflop_per_step_per_gpu": round(B * cold / 1e12, 2),
                        "warm_ms_per_step": round(warm_ms, 3) if warm_ms == warm_ms else None, "warm_steps_per_s": round(world * 1e3 / warm_ms, 2) if warm_ms == warm_ms else None,

@@ -81,3 +81,27 @@ def test_gloo_world2_allgather_equals_full_batch(global_batch):
         # per-sample independence: sharded == full batch (fp32 CPU matmuls may differ in blocking -> tight tolerance)
         assert torch.allclose(g, full, atol=5e-6, rtol=0), (g - full).abs().max().item()
     assert torch.equal(res[0][1], res[1][1]), "all ranks must hold identical gathered logits"
+
+
+def test_bench_dry_ranks_8_executes_the_whole_multi_rank_host_path():
+    """the first 8-GPU run of bench.py must not be the first run of its N > 1 plumbing. `bench.py --dry-ranks 8` re-launches
+    itself with 8 ranks over gloo and walks the same code path as the RCCL run -- LogitsComm creation (id drawn by rank 0, broadcast, every
+    rank joins: here a StubCommBackend checks that all ranks hold the same id), the agreement all-reduce, the rank-0-written state-dict
+    cache, K steps with barrier / max-over-ranks timing and per-rank all-gather brackets, a content check of the gathered logits
+    ([rank 0 rows, rank 1 rows, ...]), teardown -- and prints one JSON line marked dry_run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-ranks", "8", "--steps", "2", "--warmup", "1", "--batch", "16"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["value"] is None and d["steps"] == 2
+    c = d["config"]
+    assert c["global_batch"] == 128 and c["parallelism"] == "dp8" and "StubCommBackend" in c["collective"]
+    assert c["stub_calls_rank0"][:3] == ["unique_id", "create", "all_gather"]
+    assert "rank 0 built it once" in c["state_dict"]
+    assert len(c["ranks"]["ms_per_step_own"]) == 8 and len(c["ranks"]["allgather_us"]) == 8

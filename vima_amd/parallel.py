@@ -14,21 +14,67 @@ travels to the other ranks through the already initialised torch.distributed gro
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
 
 
-class LogitsComm:
-    """RCCL communicator of the data-parallel policy path, owned by libvima_hip.so (C ABI: vima_comm_*)."""
+class StubCommBackend:
+    """Stand-in for the four vima_comm_* entry points of the C ABI on machines without a GPU: same call ORDER and the same contract
+    (rank 0 draws an id, every rank joins with it, the collective is an all-gather of equal row blocks, destroy) over the already
+    initialised torch.distributed group. It exists so that the whole N > 1 host path of bench.py -- communicator creation order, the id
+    broadcast, the agreement all-reduce, max-over-ranks timing, teardown -- can be EXECUTED at world size 8 in the CPU suite
+    (`bench.py --dry-ranks 8`, tests/test_parallel.py); it is never a measurement and never the product path."""
+    ID_BYTES = 128
 
-    def __init__(self, device, group=None, rank: int | None = None, world: int | None = None, unique_id: bytes | None = None):
-        from . import _lib
-        self._lib = _lib.load()
-        self._check = _lib.check
+    def __init__(self, group=None):
+        self.group = group
+        self.joined = None
+        self.calls = []
+
+    def unique_id(self) -> bytes:
+        self.calls.append("unique_id")
+        return (b"vima-stub-comm-id:" + os.urandom(16).hex().encode()).ljust(self.ID_BYTES, b"\0")
+
+    def create(self, unique_id: bytes, world: int, rank: int, device_index: int):
+        self.calls.append("create")
+        assert len(unique_id) == self.ID_BYTES and unique_id.startswith(b"vima-stub-comm-id:")
+        # every rank must hold the SAME id (the real ncclCommInitRank would hang or fail otherwise): checked collectively
+        ids = [None] * world
+        dist.all_gather_object(ids, unique_id, group=self.group)
+        if any(i != ids[0] for i in ids):
+            raise RuntimeError("LogitsComm (stub): the ranks joined with different communicator ids")
+        self.joined = (world, rank)
+
+    def all_gather(self, local: torch.Tensor, rows_per_rank: int, world: int) -> torch.Tensor:
+        self.calls.append("all_gather")
+        out = local.new_empty(world * rows_per_rank, local.shape[1])
+        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
+    def destroy(self):
+        self.calls.append("destroy")
+        self.joined = None
+
+
+class LogitsComm:
+    """RCCL communicator of the data-parallel policy path, owned by libvima_hip.so (C ABI: vima_comm_*). `backend` replaces the four
+    entry points (StubCommBackend: the CPU dry run of the N > 1 host path); everything else -- who draws the id, how it travels, the
+    order of the calls -- is this class and is the same in both."""
+
+    def __init__(self, device, group=None, rank: int | None = None, world: int | None = None, unique_id: bytes | None = None, backend=None):
         device = torch.device(device)
-        if device.type != "cuda":
-            raise RuntimeError("LogitsComm needs a GPU device (RCCL); the CPU tests use torch.distributed/gloo instead")
+        self._backend = backend
+        if backend is None:
+            from . import _lib
+            self._lib = _lib.load()
+            self._check = _lib.check
+            id_bytes = _lib.COMM_ID_BYTES
+            if device.type != "cuda":
+                raise RuntimeError("LogitsComm needs a GPU device (RCCL); the CPU tests use torch.distributed/gloo or a StubCommBackend instead")
+        else:
+            id_bytes = backend.ID_BYTES
         self.device = device
         if rank is None or world is None:
             rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -36,22 +82,33 @@ class LogitsComm:
         if unique_id is None:
             box = [None]
             if rank == 0:
-                buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
-                self._check(self._lib.vima_comm_unique_id(buf))
-                box[0] = buf.raw
+                if backend is None:
+                    buf = ctypes.create_string_buffer(id_bytes)
+                    self._check(self._lib.vima_comm_unique_id(buf))
+                    box[0] = buf.raw
+                else:
+                    box[0] = backend.unique_id()
             if world > 1:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             unique_id = box[0]
-        assert len(unique_id) == _lib.COMM_ID_BYTES
-        h = ctypes.c_void_p()
-        idx = device.index if device.index is not None else torch.cuda.current_device()
-        self._check(self._lib.vima_comm_create(unique_id, world, rank, idx, ctypes.byref(h)))
-        self._h = h
+        assert len(unique_id) == id_bytes
+        self._h = None
+        if backend is None:
+            h = ctypes.c_void_p()
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            self._check(self._lib.vima_comm_create(unique_id, world, rank, idx, ctypes.byref(h)))
+            self._h = h
+        else:
+            backend.create(unique_id, world, rank, device.index or 0)
+            self._h = backend
 
     def all_gather(self, local: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
         """local f32 [rows_per_rank, W] (contiguous, on this rank's GPU) -> [world * rows_per_rank, W]; enqueued on the
         current stream, no host synchronisation."""
-        assert local.is_cuda and local.dtype == torch.float32 and local.is_contiguous() and local.shape[0] == rows_per_rank
+        assert local.dtype == torch.float32 and local.is_contiguous() and local.shape[0] == rows_per_rank
+        if self._backend is not None:
+            return self._backend.all_gather(local, rows_per_rank, self.world)
+        assert local.is_cuda
         out = local.new_empty(self.world * rows_per_rank, local.shape[1])
         stream = ctypes.c_void_p(torch.cuda.current_stream(local.device).cuda_stream)
         self._check(self._lib.vima_allgather_logits(self._h, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(out.data_ptr()),
@@ -60,7 +117,10 @@ class LogitsComm:
 
     def close(self):
         if getattr(self, "_h", None) is not None:
-            self._lib.vima_comm_destroy(self._h)
+            if self._backend is not None:
+                self._backend.destroy()
+            else:
+                self._lib.vima_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):
