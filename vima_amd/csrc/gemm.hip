@@ -36,9 +36,9 @@ namespace vima {
 namespace {
 
 // The main-loop ablation builds behind DESIGN.md 4.2 (timing only, wrong results) are NOT part of this source:
-// scripts/ablate/gemm_ablate.patch re-creates them on a scratch copy (scripts/build_ablate.sh). Round 4's epilogue / cache-policy
-// experiments ARE here, behind macros only the lab builds define (scripts/micro/gemm_lab.hip with
-// -DVIMA_LAB_NORES | _NOSTORE | _SKEW=n: timing only; -DVIMA_LAB_NT_A | _NT_ST: non-temporal A loads / output stores, correct results).
+// scripts/ablate/gemm_ablate.patch re-creates them on a scratch copy (scripts/build_ablate.sh), and so does scripts/ablate/gemm_lab_variants.patch
+// for round 4's epilogue / cache-policy experiments (-DVIMA_LAB_NORES | _NOSTORE | _SKEW=n timing only,
+// -DVIMA_LAB_NT_A | _NT_ST non-temporal A loads / output stores; scripts/micro/build_gemm_lab.sh applies it). The shipped kernels have ONE schedule.
 #ifdef VIMA_GEMM_LAB
 constexpr bool kLab = true;    // scripts/micro/gemm_lab.hip: only the 256x256 bf16 kernels are instantiated (compile time)
 #else
@@ -827,11 +827,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const char* q = auxp + (long long)(mi * 32 + it * RPI) * aux_ld + ni * 32 * (EPI == 3 ? 4 : 2);
-#ifdef VIMA_LAB_NORES   // timing-only ablation (scripts/micro/gemm_lab): the per-row operand is never loaded
-      asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(dst[it][0]), "=v"(dst[it][1]), "=v"(dst[it][2]), "=v"(dst[it][3]) : "v"(q));
-#else
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
-#endif
     }
   };
   if (aux_on) issue_aux(0, aux[0]);
@@ -848,11 +844,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
     for (int it = 0; it < NIT; ++it) {
       const long long m = mrow0 + mi * 32 + it * RPI;
       if constexpr (WIDE8) {
-#ifdef VIMA_LAB_NOSTORE   // timing-only ablation: the output tile is never written
-        asm volatile("" ::"v"(h_o[it].x), "v"(h_o[it].y), "v"(h_o[it].z), "v"(h_o[it].w));
-#else
         if (!O8 || outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = h_o[it];
-#endif
         if (EPI == 4 && O8 && p.out8) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.out8) + m * p.ld8 + n) = h_o8[it];
         if (EPI == 4 && ssq_out && (elane & 3) == 0) ssq_out[m * (p.N >> 5) + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] = h_sq[it];
       } else {
@@ -891,7 +883,6 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
        if (aux_on) {
         if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
         f32x4_t(&a)[NIT] = aux[sl & 1];
-#ifndef VIMA_LAB_NORES   // (the timing-only ablation has nothing to wait for)
         if (sl + 1 < NSLAB) {
           if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(NIT) : "memory");
           else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(NIT) : "memory");
@@ -899,7 +890,6 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]) : : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : : "memory");
         }
-#endif
        }
         if (sl > 0) emit_stores(sl - 1);
       }
@@ -945,13 +935,6 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           o.x = pack2_bf16(v[0].x, v[0].y); o.y = pack2_bf16(v[0].z, v[0].w); o.z = pack2_bf16(v[1].x, v[1].y); o.w = pack2_bf16(v[1].z, v[1].w);
           if constexpr (AUX) h_o[it] = o;
           else {
-#ifdef VIMA_LAB_NOSTORE   // timing-only ablation: the output tile is never written
-          asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
-#elif defined(VIMA_LAB_NT_ST)   // experiment: non-temporal output stores (the output is never re-read by this kernel)
-          { typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            const T* q_ = outT + m * p.ldT + n; const u32x4_t ov = {o.x, o.y, o.z, o.w};
-            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(q_), "v"(ov) : "memory"); }
-#else
           if constexpr (EPI == 5) {   // head-major: [batch][head][row][hm_D]; a tile's 256 rows lie in one batch (hm_L % 256 == 0), the lane's 8 columns in one head
             const int lg = 31 - __builtin_clz((unsigned)p.hm_D);
             const long long bq = m0 / p.hm_L;
@@ -959,7 +942,6 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
             *reinterpret_cast<uint4*>(outT + o_) = o;
           } else
           if (!O8 || outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
-#endif
           }
           if (O8 && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
             const float q = p.out8_inv;
@@ -1391,13 +1373,8 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     const unsigned koff = (unsigned)(ikt * RB);
     if (h & 1) {
       const unsigned s = koff + (h == 3 ? stepA1 : 0u);
-#ifdef VIMA_LAB_NT_A
-      glds16_asm_s_nt(A, offA[0] + s, dst);
-      glds16_asm_s_nt(A, offA[1] + s, dst + 8 * 1024);
-#else
       glds16_asm_s(A, offA[0] + s, dst);
       glds16_asm_s(A, offA[1] + s, dst + 8 * 1024);
-#endif
     } else {
       const unsigned s = koff + (h == 2 ? stepB1 : 0u);
       glds16_asm_s(W, offW[0] + s, dst);
@@ -1415,9 +1392,6 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
 
   int cv = next_valid(blockIdx.x);
   if (cv < 0) return;
-#ifdef VIMA_LAB_SKEW   // timing-only experiment (scripts/micro/gemm_lab): every other CU of an XCD starts VIMA_LAB_SKEW x 8k clocks late
-  if ((blockIdx.x >> 3) & 1) { for (int i = 0; i < VIMA_LAB_SKEW; ++i) __builtin_amdgcn_s_sleep(127); }
-#endif
   iv = cv;
   set_ptrs(iv);
   // prologue: K-tile 0 completely, K-tile 1 up to B1 (its A1 is phase 1's request)
