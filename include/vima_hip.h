@@ -254,6 +254,11 @@ int vima_t5_bucket(int relative_position);
  *                            "gemm_resident" [1] underfilled grids on gemm_resident_kernel ((almost) the whole K extent in flight, one
  *                                               barrier per chunk of K-slices; bit-identical to the ring tiles), 0: the 4-deep ring tiles
  *                            "gemm_res_maxwg" [256] largest grid (workgroups) gemm_resident_kernel takes for M > 32
+ *                            "gemm_skinny"  [1] GEMMs of at most 32 rows (one env step at batch <= 3, the action head ...) on gemm_skinny_kernel: K split
+ *                                               over the 4 / 8 / 16 waves of a workgroup, operands straight from global memory, 8 / 16 / 32-column tiles.
+ *                                               A DIFFERENT summation order than every other tile (which all agree bit for bit): a sample evaluated alone and the
+ *                                               same sample inside a large batch then agree to bf16 rounding (~2e-4 on logits of 0.08), not bit for bit;
+ *                                               0 = the resident 32x32 tile for these shapes
  *                            "gemm_res_nch" [0] chunk buffers of its LDS ring: 0 = default (4 / 5 / 4 for the 32x32 / 64x32 / 64x64 tile: 128 KiB),
  *                                               up to 5 / 6 / 5 (160 KiB)
  *                            "gemm_splitk"  [0] deterministic two-pass split-K for underfilled grids with K >= 1536
@@ -272,7 +277,14 @@ int vima_t5_bucket(int relative_position);
  *                            "kv_headmajor" [1] decoder prompt K / V written head-major ([B][2 heads][Lp][head dim]) where the projection runs on the
  *                                               persistent 256x256 GEMM (batch x prompt large enough): same values, contiguous reads in the cross attention
  *                            "geglu_pair"   [1] a GEGLU whose two products read the same input (the decoder blocks' MLP) as ONE GEMM launch over
- *                                               block-interleaved weights where the grid is between the dual-accumulator and the 256x256 forms: same values
+ *                                               block-interleaved weights (128x128 ring tile, or the persistent 256x256 kernel's pair epilogue from 160 full
+ *                                               tiles of the interleaved [M, 8E] problem on: 2048 rows at E = 768) where the grid is beyond the
+ *                                               dual-accumulator form: same values
+ *                            "ln_fuse"      [1] decoder LayerNorms (bf16 precisions): ln_2 of layer i and the query pre-LN of XAttention in layer i + 1 as ONE
+ *                                               launch (bit-identical); the pre-LN in front of XAttention's feed-forward folded into the GEMMs either side of
+ *                                               it (sums / sums of squares per 32 columns from attention_out's epilogue, mean / rstd applied to the GELU'd factor
+ *                                               in the GEGLU pair's epilogue, gamma folded into the weight) where a pair form exists for the row count --
+ *                                               the operand is then bf16(a) instead of bf16(LN(a)): same precision class, different rounding point
  *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass
@@ -295,11 +307,11 @@ int vima_prof_read(VimaHandle* h, double out_ms[3], int64_t out_launches[3], dou
  * residual, write the fp32 stream [+ operand-type copy + RMS partials]: the HBM-heavy ones), 1 = attention, 2 = other. */
 int vima_prof_read_ex(VimaHandle* h, double out_ms[4], int64_t out_launches[4], double out_flops[4], double out_bytes[4]);
 /* The GEMM launches recorded since vima_prof_enable, grouped by the KERNEL the launcher chose: ids[i] = kind * 1000 +
- * (activation + 1) * 10 + epilogue (1 bf16 output, 2 GEGLU gate, 3 fp32 output +- residual, 4 bf16 residual stream, 5 bf16 output written head-major),
+ * (activation + 1) * 10 + epilogue (1 bf16 output, 2 GEGLU gate, 3 fp32 output +- residual, 4 bf16 residual stream, 5 bf16 output written head-major, 6 GEGLU pair over block-interleaved weights),
  * kind 1 gemm_pp_kernel<ACT, EPI>, 2 gemm_persistent_kernel<ACT, EPI>, 3 gemm_wide_kernel,
  * 4..7 gemm_kernel with the 256x256 / 128x128 / 64x64 / 32x64 tile (kind 5 with N = 8 x embed_dim: the block-interleaved GEGLU pair, two products per launch), 8 two-pass split-K, 10..12 gemm_resident_kernel with the
  * 32x32 / 64x32 / 64x64 tile (also the grouped launch of the action head's last layers), 15 / 16 its GEGLU-pair form (two products per launch:
- * 32x32 / 64x64 tile); per kernel the summed milliseconds,
+ * 32x32 / 64x64 tile), 17 / 18 gemm_skinny_kernel (at most 32 rows) / its GEGLU-pair form; per kernel the summed milliseconds,
  * launches, algorithmic FLOPs and algorithmic HBM bytes. Returns the number of kernels (<= max_n) or a negative error; does
  * NOT reset the records (call it before vima_prof_read / vima_prof_read_ex). */
 int vima_prof_read_gemm_kernels(VimaHandle* h, int max_n, int32_t* ids, double* ms, int64_t* launches, double* flops, double* bytes);

@@ -42,7 +42,7 @@ def test_allgather_logits_c_abi_world1():
     comm.close()
 
 
-def _worker(rank, world, port, global_batch, q):
+def _worker(rank, world, port, global_batch, q, skinny=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,6 +53,7 @@ def _worker(rank, world, port, global_batch, q):
         sd = syn.make_state_dict(cfg, 0)
         pol = VIMAPolicy(**cfg.ctor_kwargs(), precision="bf16", device=dev)
         pol.load_state_dict(sd, strict=True)
+        pol.set_option("gemm_skinny", skinny)
         prompts = syn.make_prompt(global_batch, n_segments=2, words_per_segment=3, q_per_view=2, seed=5)
         obs = syn.make_obs(1, global_batch, 2, seed=6)
 
@@ -71,15 +72,17 @@ def _worker(rank, world, port, global_batch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("global_batch", [6, 7])
-def test_two_ranks_hip_shards_equal_full_batch(global_batch):
+@pytest.mark.parametrize("global_batch,skinny", [(6, 0), (7, 0), (6, 1)])
+def test_two_ranks_hip_shards_equal_full_batch(global_batch, skinny):
     """World size 2, per-shard compute = the HIP policy: concat(shard logits) == full-batch logits (samples are
-    independent end to end; the GEMM tiles accumulate K in the same order at every batch size, so the match is exact up
-    to 1e-6) and both ranks hold identical gathered logits. Odd global batch exercises the padded ragged tail."""
+    independent end to end) and both ranks hold identical gathered logits. Odd global batch exercises the padded ragged tail.
+    gemm_skinny = 0: every GEMM tile accumulates K in the same order at every batch size, so the match is exact up to 1e-6.
+    Default (gemm_skinny = 1, round 5): GEMMs of at most 32 rows take the K-split kernel, so a 3-sample shard (e.g. 24 prompt-object rows) and the
+    6-sample batch (48 rows) sum some products in a different order -- equal to bf16 rounding, a fraction of the 1e-3 gate."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, global_batch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, global_batch, q, skinny)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
@@ -89,7 +92,7 @@ def test_two_ranks_hip_shards_equal_full_batch(global_batch):
     full = [f for f, _ in res if f is not None][0]
     for _, g in res:
         assert g.shape == (global_batch, 700)
-        assert torch.allclose(g, full, atol=1e-6, rtol=0), (g - full).abs().max()
+        assert torch.allclose(g, full, atol=1e-6 if not skinny else 5e-4, rtol=0), (g - full).abs().max()
     assert torch.equal(res[0][1], res[1][1])
 
 
