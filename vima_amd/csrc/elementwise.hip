@@ -544,7 +544,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void prompt_pos_kernel(const float* __restrict__ prompt, long long sb, long long sl,
                                                           const uint8_t* __restrict__ mask,
                                                           const float* __restrict__ pos_table, int n_pos, T* out, int B,
-                                                          int Lp, int E) {
+                                                          int Lp, int E, int slab) {
   extern __shared__ int pos_dyn[];
   __shared__ int part[256];
   const int b = blockIdx.x;
@@ -576,10 +576,11 @@ __global__ __launch_bounds__(256) void prompt_pos_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  // blockIdx.y selects a slab of 64 positions to copy (the cheap scan above is redone per slab for parallelism)
+  // blockIdx.y selects a slab of `slab` positions to copy (the cheap scan above is redone per slab for parallelism): 64, or 8 when the batch is so
+  // small that 64-position slabs would leave the copy to a handful of CUs (a CU streams ~25 GB/s: one prompt on 8 workgroups took 29 us)
   const int e4 = E >> 2;
-  const int lbeg = blockIdx.y * 64;
-  const int lend = lbeg + 64 < Lp ? lbeg + 64 : Lp;
+  const int lbeg = blockIdx.y * slab;
+  const int lend = lbeg + slab < Lp ? lbeg + slab : Lp;
   for (int i = threadIdx.x + lbeg * e4; i < lend * e4; i += 256) {
     const int l = i / e4, c = (i % e4) * 4;
     const float4 a = *reinterpret_cast<const float4*>(prompt + b * sb + l * sl + c);
@@ -887,12 +888,13 @@ int launch_prompt_pos(const float* prompt, long long sb, long long sl, const uin
   if (B <= 0 || Lp <= 0) return 0;
   if (E % 4 || sb % 4 || sl % 4) return (int)hipErrorInvalidValue;
   const size_t sh = (size_t)Lp * sizeof(int);
+  const int slab = (long long)B * ((Lp + 63) / 64) >= 512 ? 64 : 8;
   if (is_bf16)
-    hipLaunchKernelGGL(prompt_pos_kernel<bf16_t>, dim3(B, (Lp + 63) / 64), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
-                       (bf16_t*)outT, B, Lp, E);
+    hipLaunchKernelGGL(prompt_pos_kernel<bf16_t>, dim3(B, (Lp + slab - 1) / slab), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
+                       (bf16_t*)outT, B, Lp, E, slab);
   else
-    hipLaunchKernelGGL(prompt_pos_kernel<float>, dim3(B, (Lp + 63) / 64), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
-                       (float*)outT, B, Lp, E);
+    hipLaunchKernelGGL(prompt_pos_kernel<float>, dim3(B, (Lp + slab - 1) / slab), dim3(256), sh, st, prompt, sb, sl, mask, pos_table, n_pos,
+                       (float*)outT, B, Lp, E, slab);
   return (int)hipGetLastError();
 }
 
