@@ -1424,10 +1424,23 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     float rscv[MI];
     int tl31 = l31;
     asm volatile("" : "+v"(tl31));
+    // Fused-RMSNorm row statistics (E = 768: 24 partial sums of squares per row, 96 contiguous bytes). Loaded into registers here they cost every
+    // tile an exposed round trip to L2 / HBM (the consumer GEMMs of the T5 stack ran 2-2.5 % slower for it). Instead wave w requests the partials of
+    // tile rows [32 w, 32 w + 32) -- 3 KiB, contiguous -- by LDS-DMA into ITS epilogue slab (idle until the epilogue); they land behind the main
+    // loop's own counted waits (these requests are OLDER than every half-tile request of this tile, VMEM retires in order, and the launcher
+    // guarantees nk >= 2, i.e. at least one vmcnt wait + barrier per tile) and are reduced after the loop, from LDS, in rms_row_scale's order.
+    const bool rs_dma = (EPI == 1 || EPI == 5) && p.rs_ssq && p.rs_parts == 24;
+    if (rs_dma) {
+      const unsigned so = (unsigned)(m0 + w * 32) * 96u + (unsigned)lane * 16u;
+      const unsigned dst = smem_base + (unsigned)(EPI_OFF + w * 4096);
+      glds16_asm_s(p.rs_ssq, so, dst);
+      glds16_asm_s(p.rs_ssq, so + 1024u, dst + 1024u);
+      glds16_asm_s(p.rs_ssq, so + 2048u, dst + 2048u);
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       rscv[mi] = 1.0f;
-      if ((EPI == 1 || EPI == 5) && p.rs_ssq) {
+      if ((EPI == 1 || EPI == 5) && p.rs_ssq && !rs_dma) {
         const int mr = m0 + wm * (MI * 32) + mi * 32 + tl31;
         rscv[mi] = rms_row_scale(p.rs_ssq, p.rs_parts, mr, p.rs_invk, p.rs_eps);
       }
@@ -1532,6 +1545,21 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (EPI == 1 || EPI == 5) {
+      if (rs_dma) {   // rows wm * 128 + mi * 32 + l31 of the tile: slab of wave wm * 4 + mi, row l31
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float* q = reinterpret_cast<const float*>(smem + EPI_OFF + (wm * 4 + mi) * 4096) + tl31 * 24;
+          rscv[mi] = __builtin_amdgcn_rsqf(ln_tree24(q) * p.rs_invk + p.rs_eps);
+        }
+        // every wave of the workgroup has read its rows before any wave's epilogue overwrites a slab (one more workgroup barrier per tile; the two
+        // 128-row halves have re-joined above, so it pairs up)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" : "+v"(rscv[0]), "+v"(rscv[1]), "+v"(rscv[2]), "+v"(rscv[3]));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
     stamp(2);
     if constexpr (EPI == 6) {
       if (p.rs_sum) tile_epilogue_256_pair<true>(p, acc, smem + EPI_OFF + w * 4096, lane, m0, n0, wm, wn);
