@@ -236,6 +236,38 @@ def test_small_tiles_match_128_tile_bitwise():
         pol.set_option("gemm_skinny", 1)
 
 
+def test_pp_kernel_flat_enumeration_is_bit_identical():
+    """gemm_pp_kernel drops its XCD raster (A panels padded to a multiple of 8, panel tm on XCD tm % 8) for small grids where the padding costs a
+    whole round -- 9 panels x 24 n-tiles, the GEGLU pair of an incremental env step at batch 256 (M = 2304): XCD 0 would get 48 tiles for 32
+    workgroups. Same tiles, other workgroups: the output must be BIT-identical with the option off, and right against fp64."""
+    pol = bare_policy("bf16")
+    pol.set_option("op_bf16_out", 1)
+    g = torch.Generator().manual_seed(21)
+    try:
+        for M, N, K in [(2304, 6144, 768), (2304, 4608, 768), (256 * 17, 3072, 768), (2304, 6144, 3072)]:
+            A, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            outs = []
+            for flat in (1, 0):
+                pol.set_option("gemm_flat", flat)
+                out = torch.full((M, N), float("nan"), device="cuda")
+                pol.prof_enable(True)
+                _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(A), ptr(W), ptr(b), None, None, M, N, K, 3, ptr(out), pol._stream()))   # QuickGELU
+                torch.cuda.synchronize()
+                kernels = pol.prof_read_gemm_kernels()
+                pol.prof_enable(False)
+                assert any(k.startswith("vima::gemm_pp_kernel") for k in kernels), list(kernels)
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (M, N, K)
+            ab, wb = A.to(torch.bfloat16).double(), W.to(torch.bfloat16).double()
+            pre = ab @ wb.T + b.double()
+            ref = pre * torch.sigmoid(1.702 * pre)
+            assert max_rel(outs[0].double(), ref) < 6e-3, (M, N, K)
+    finally:
+        pol.set_option("gemm_flat", 1)
+        pol.set_option("op_bf16_out", 0)
+
+
 def test_resident_kernel_matches_ring_tiles_bitwise():
     """gemm_resident_kernel (underfilled grids: (almost) the whole K extent in flight, one barrier per chunk of K-slices) walks K
     in the same order with the same matrix instruction as the ring tiles: every tile shape of it (gemm_tile 10 / 11 / 12 =

@@ -274,6 +274,7 @@ struct GemmDev {
   void* out8; int ld8; float out8_inv;   // optional fp8 e4m3 copy of the bf16 output: e4m3(value * out8_inv), saturating at 448
   int mtiles, ntiles;
   int vtotal;   // persistent kernel: number of virtual tile ids = ceil8(mtiles) * ntiles
+  int flat;     // gemm_pp_kernel: 1 = virtual tile v is tile (v % mtiles, v / mtiles), no XCD raster (small grids, see launch_pp)
   int raster;   // 0: XCD walks the n-tiles of one A panel; 1: XCD keeps a group of `ngroup` n-tiles (W panels) resident
   int ngroup;   //    and walks its A panels through it; 2: plain row-major (no XCD awareness)
   int epi_lds;  // 1 = LDS-transposed (row-contiguous) vector epilogue, 0 = direct per-lane epilogue
@@ -1329,6 +1330,7 @@ __global__ __launch_bounds__(TileL::THREADS, 2) void gemm_pp_kernel(const GemmDe
   // panels -- small enough to stay in its 4-MiB L2 -- before it moves to the next group (the A panels are then fetched once
   // per group; with one group the W panels of a wide N are re-streamed from beyond L2 for every A panel).
   auto tile_at = [&](int v, int& tm, int& tn) {
+    if (p.flat) { tn = v / p.mtiles; tm = v - tn * p.mtiles; return; }
     const int idx = v >> 3;
     const int mtx = (p.mtiles + 7) >> 3;                // A panels per XCD (incl. padding panels)
     const int per_group = mtx * p.ngroup;
@@ -1887,6 +1889,8 @@ int g_env_res_nch = -1;
 VIMA_KNOB(gemm_res_nch, gemm_res_nch, "VIMA_GEMM_RES_NCH", g_env_res_nch, 0)
 int g_env_skinny = -1;
 VIMA_KNOB(gemm_skinny, gemm_skinny, "VIMA_GEMM_SKINNY", g_env_skinny, 1)
+int g_env_flat = -1;
+VIMA_KNOB(gemm_flat, gemm_flat, "VIMA_GEMM_FLAT", g_env_flat, 1)
 #undef VIMA_KNOB
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -2054,6 +2058,17 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
     }
   }
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
+  // The XCD raster pads the A panels to a multiple of 8 (panel tm lives on XCD tm % 8): with mtiles % 8 small and a grid of about one tile per CU
+  // the panels of the last group pile up on a few XCDs -- M = 2304 (an incremental env step at batch 256: 9 panels) x 24 n-tiles gave XCD 0 48 tiles
+  // for its 32 workgroups, i.e. TWO rounds for 216 tiles (49 us instead of 30). Where the plain enumeration needs fewer rounds and the problem is
+  // small enough for L2 placement not to matter (<= 2 tiles per workgroup) the raster is dropped.
+  d.flat = 0;
+  {
+    const long long tiles = (long long)d.mtiles * d.ntiles;
+    const long long per_xcd = (long long)((d.mtiles + 7) / 8) * d.ntiles, wg_xcd = g_num_cu / 8;
+    const long long rounds_raster = (per_xcd + wg_xcd - 1) / wg_xcd, rounds_flat = (tiles + g_num_cu - 1) / g_num_cu;
+    if (tiles <= 2LL * g_num_cu && rounds_flat < rounds_raster && gemm_flat(a.tune)) { d.flat = 1; d.vtotal = (int)tiles; }
+  }
   const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
   int epi = 0;
   if (a.rb == 0) {

@@ -20,6 +20,7 @@ struct Tuning {
   int gemm_resident = -1;  // VIMA_GEMM_RESIDENT 1 = underfilled grids on gemm_resident_kernel (whole K in flight; default), 0 = the 4-deep ring tiles
   int gemm_res_maxwg = -1; // VIMA_GEMM_RES_MAXWG largest grid (workgroups) that kernel takes at M > 32 (default 256 = one per CU)
   int gemm_skinny = -1;    // VIMA_GEMM_SKINNY   1 = GEMMs of at most 32 rows on gemm_skinny_kernel (K split over the waves of a workgroup; default), 0 = the resident 32x32 tile (bit-identical to every other tile)
+  int gemm_flat = -1;        // VIMA_GEMM_FLAT     1: gemm_pp_kernel drops the XCD raster for small grids where it costs a round (default); 0: never
   int gemm_res_nch = -1;   // VIMA_GEMM_RES_NCH  chunk buffers of that kernel's LDS ring (0 = default: 4 / 5 / 4 = up to 128 KiB; max 5 / 6 / 5 = 160 KiB)
   long long* gemm_dbg = nullptr;   // device buffer [blocks*4] of shader-clock stamps (nullptr = off)
   int attn_split = -1;     // 1 = split-key 4-wave kernel for Lq <= 32 (default), 0 = one-wave kernel

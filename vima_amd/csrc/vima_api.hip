@@ -1656,6 +1656,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_res_maxwg") h->tune.gemm_res_maxwg = (int)value;
   else if (k == "gemm_res_nch") h->tune.gemm_res_nch = (int)value;
   else if (k == "gemm_skinny") h->tune.gemm_skinny = (int)value;
+  else if (k == "gemm_flat") h->tune.gemm_flat = (int)value;
 
   else if (k == "gemm_dbg_ptr") h->tune.gemm_dbg = reinterpret_cast<long long*>((uintptr_t)value);
   else if (k == "attn4_min_lq") h->tune.attn4_min_lq = (int)value;
