@@ -259,6 +259,9 @@ int vima_t5_bucket(int relative_position);
  *                                               A DIFFERENT summation order than every other tile (which all agree bit for bit): a sample evaluated alone and the
  *                                               same sample inside a large batch then agree to bf16 rounding (~2e-4 on logits of 0.08), not bit for bit;
  *                                               0 = the resident 32x32 tile for these shapes
+ *                            "gemm_flat"    [1] gemm_pp_kernel enumerates its tiles plainly (no XCD raster) where the raster's padding of the A panels to a
+ *                                               multiple of 8 would cost a round and the grid is at most two tiles per workgroup (M = 2304: the GEGLU pair
+ *                                               of an incremental env step at batch 256); bit-identical, 0 = always the raster
  *                            "gemm_res_nch" [0] chunk buffers of its LDS ring: 0 = default (4 / 5 / 4 for the 32x32 / 64x32 / 64x64 tile: 128 KiB),
  *                                               up to 5 / 6 / 5 (160 KiB)
  *                            "gemm_splitk"  [0] deterministic two-pass split-K for underfilled grids with K >= 1536
