@@ -69,12 +69,13 @@ int main(int argc, char** argv) {
       if (nm.empty()) continue;
       Variant v; v.name = nm;
       v.t.gemm_variant = 1; v.t.gemm_tile = 0; v.t.gemm_raster = 0; v.t.gemm_epi = 1; v.t.gemm_persist = 1; v.t.gemm_small = 1;
-      v.t.gemm_wide = 0; v.t.gemm_pp = 0; v.t.gemm_splitk = 0;
+      v.t.gemm_wide = 0; v.t.gemm_pp = 0; v.t.gemm_splitk = 0; v.t.gemm_q4 = 0;
       if (nm == "persist") {}
       else if (nm == "pp") v.t.gemm_pp = 1;
       else if (nm == "tile") v.t.gemm_persist = 0;
       else if (nm == "fp8") v.t.gemm_pp = 1;     // fp8 e4m3 A and W, v_mfma_scale_f32_32x32x64_f8f6f4 (own operands / reference)
       else if (nm == "wide") v.t.gemm_wide = 1;
+      else if (nm == "q4") { v.t.gemm_pp = 1; v.t.gemm_q4 = 1; }   // 256x384, four waves (one per SIMD)
       else { printf("unknown variant %s\n", nm.c_str()); return 1; }
       vars.push_back(v);
     }
@@ -182,6 +183,22 @@ int main(int argc, char** argv) {
         for (int i = 16; i < 14 + nit; ++i) printf(" %.0f", acc[i] / c2);
         printf("\n");
       }
+      if (vars[vi].name == "q4" && getenv("KTSTAMPS")) {   // -DVIMA_Q4_KT_STAMPS builds: mean clocks of each K-tile of a tile (first 32), from the start of its main loop
+        const int nkt = std::min(K / 64, 32);
+        const int nb4 = ((M + 255) / 256 + 7) / 8 * 8 * (N / 384);
+        std::vector<double> acc(32, 0.0); int c2 = 0;
+        for (int b = 0; b < nb4; ++b) {
+          const long long* d = &h[(size_t)b * 8];
+          const long long* it = &h[(size_t)nb4 * 8 + (size_t)b * 32];
+          if (d[3] <= 0) continue;
+          long long prev = d[1];
+          for (int i = 0; i < nkt; ++i) { acc[i] += (double)(it[i] - prev); prev = it[i]; }
+          ++c2;
+        }
+        printf("  [q4] clocks per K-tile:");
+        for (int i = 0; i < nkt; ++i) printf(" %.0f", acc[i] / std::max(c2, 1));
+        printf("\n");
+      }
       double pro = 0, mainl = 0, epil = 0, rt = 0; int cnt = 0;
       for (int b = 0; b < nblk; ++b) {
         const long long* d = &h[(size_t)b * 8];
@@ -206,6 +223,13 @@ int main(int argc, char** argv) {
       if (memcmp(&h0[i * es], &h1[i * es], es)) { if (first < 0) first = (long long)i; ++diff; }
     printf("  %s vs %s: %lld of %lld elements differ%s", vars[vi].name.c_str(), vars[0].name.c_str(), diff, (long long)(out_bytes / es), diff ? "" : " (bit-identical)\n");
     if (diff) printf(" (first at row %lld col %lld)\n", first / N, first % N);
+    if (diff && getenv("DIFFMAP")) {   // where inside a 256 x 384 tile the differing elements sit: 8 x 12 blocks of 32 x 32, then by tile row
+      long long hist[8][12] = {}, byrow[32] = {};
+      for (size_t i = 0; i < out_bytes / es; ++i)
+        if (memcmp(&h0[i * es], &h1[i * es], es)) { const long long r = i / N, c = i % N; ++hist[(r % 256) / 32][(c % 384) / 32]; ++byrow[r % 32]; }
+      for (int a = 0; a < 8; ++a) { printf("    mi-block %d:", a); for (int b = 0; b < 12; ++b) printf(" %8lld", hist[a][b]); printf("\n"); }
+      printf("    by row %% 32:"); for (int a = 0; a < 32; ++a) printf(" %lld", byrow[a]); printf("\n");
+    }
   }
   // host fp64 reference on sampled entries (epi 1 / act 0 / no bias only: the raw product), transpose-detecting (random data)
   if (epi == 1 && act == 0 && !bias) {

@@ -749,11 +749,11 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // HAS_BIAS / HAS_RS (fused-RMSNorm row scale) are compile-time here: as runtime flags hipcc turned the conditional adds into
 // v_pk_add + one v_cndmask per value and kept the x rsc multiply -- 256 of the 321 VALU instructions per wave of a
 // bias-less, scale-less epilogue (every T5 GEMM) did nothing, and the epilogue is VALU-issue-bound (2 waves per SIMD).
-template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS, bool OUT8>
-__device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
+template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS, bool OUT8, int NI = 2>   // NI: 32-column blocks per wave (2: the 256x256 kernels' 128x64 block; 6: gemm_q4_kernel's 128x192)
+__device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f32x16_t (&acc)[4][NI], const float (&rscv)[4], char* slab,
                                                        int lane, int m0, int n0, int wm, int wn) {
   using T = bf16_t;
-  constexpr int MI = 4, NI = 2;
+  constexpr int MI = 4;
   const int act = ACT >= 0 ? ACT : p.act;
   // ---------------------------------------------------------------- epilogue (32x32 fp32 slabs, private LDS region)
   // acc[mi][ni][4q+e] = C[m0 + wm*128 + mi*32 + l31][n0 + wn*64 + ni*32 + 8q + 4hi + e]
@@ -942,7 +942,15 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
             const long long o_ = bq * (long long)p.hm_L * (p.N - p.hm_D) + m * p.hm_D + ((long long)(n >> lg) * p.hm_L << lg) + (n & (p.hm_D - 1));
             *reinterpret_cast<uint4*>(outT + o_) = o;
           } else
+#if defined(VIMA_LAB_FULLLINE)   // timing-only (wrong values): every store instruction writes FULL 128-byte lines -- 8 lanes per row x 64 columns -- instead of 64-byte halves
+          { const long long mf = m0 + wm * (MI * 32) + mi * 32 + (ni & 1) * 16 + it * 8 + (elane >> 3);
+            const int nf = n0 + wn * (NI * 32) + (ni & ~1) * 32 + (elane & 7) * 8;
+            *reinterpret_cast<uint4*>(outT + mf * p.ldT + nf) = o; }
+#elif defined(VIMA_LAB_NOSTORE1)   // timing-only: no output stores (EPI 1)
+          asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#else
           if (!O8 || outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
+#endif
           }
           if (O8 && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
             const float q = p.out8_inv;
@@ -974,22 +982,22 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   if (AUX) emit_stores(MI * NI - 1);
 }
 
-template <int ACT, int EPI, bool W8, bool OUT8 = true>
-__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][2], const float (&rscv)[4], char* slab,
+template <int ACT, int EPI, bool W8, bool OUT8 = true, int NI = 2>
+__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][NI], const float (&rscv)[4], char* slab,
                                                   int lane, int m0, int n0, int wm, int wn) {
   const bool hb = p.bias != nullptr;                                   // kernel arguments: wave-uniform branches
   const bool hr = (EPI == 0 || EPI == 1 || EPI == 5) && p.rs_ssq != nullptr;
   if constexpr (EPI == 0 || EPI == 1 || EPI == 5) {
     if (hb) {
-      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-      else tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     } else {
-      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-      else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     }
   } else {
-    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-    else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
   }
 }
 
@@ -1853,6 +1861,8 @@ __global__ __launch_bounds__(TileW::THREADS, 2) void gemm_wide_kernel(const Gemm
   }
 }
 
+#include "gemm_q4.inc"      // gemm_q4_kernel: 256x384 tile, four waves (one per SIMD), Gray-code quadrant phases with rolling fragment reloads
+
 #ifndef VIMA_GEMM_LAB
 #include "gemm_small.inc"   // gemm_resident_kernel: underfilled grids (batch 1 .. 32, one env step), whole K in flight
 #include "gemm_skinny.inc"  // gemm_skinny_kernel: M <= 32 (one env step at batch <= 3), K split over the waves of a workgroup, operands straight from global memory
@@ -1882,6 +1892,8 @@ int g_env_wide = -1;
 VIMA_KNOB(gemm_wide, gemm_wide, "VIMA_GEMM_WIDE", g_env_wide, 0)
 int g_env_pp = -1;
 VIMA_KNOB(gemm_pp, gemm_pp, "VIMA_GEMM_PP", g_env_pp, 1)
+int g_env_q4 = -1;
+VIMA_KNOB(gemm_q4, gemm_q4, "VIMA_GEMM_Q4", g_env_q4, 0)
 int g_env_resident = -1, g_env_res_maxwg = -1;
 VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
 VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
@@ -1970,6 +1982,7 @@ int launch_persistent_inst(const GemmDev& d, int grid, hipStream_t st) {
 }
 
 int launch_persistent(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (a.split_n) return -1;   // (the column-split output is not part of the 256x256 epilogues)
   if (g_num_cu == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -2031,6 +2044,7 @@ int launch_pp_inst(const GemmDev& d, int grid, hipStream_t st) {
 // ping-pong persistent kernel (option gemm_pp): same eligibility as launch_persistent plus an even number of K-tiles and
 // bf16 weights; returns -1 when the problem does not fit it (caller falls back)
 int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (a.split_n) return -1;
   if (a.a8) { if (!a.w8 || a.K % 256 != 0) return -1; }
   else if (a.w8 || (a.K / 64) % 2 != 0 || a.out8) return -1;   // (an fp8 copy of a bf16-operand GEMM's output: launch_persistent)
   if (g_num_cu == 0) {
@@ -2038,6 +2052,7 @@ int launch_pp(GemmDev d, const GemmArgs& a, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
     g_num_cu = n / 8 * 8;
+    if (kLab) { const int lim = env_int("VIMA_GEMM_LAB_CUS", 0); if (lim >= 8 && lim < g_num_cu) g_num_cu = lim / 8 * 8; }   // lab only: run the persistent grid on a part of the chip
   }
   d.mtiles = (d.M + TileL::BM - 1) / TileL::BM;
   d.ntiles = (d.N + TileL::BN - 1) / TileL::BN;
@@ -2113,7 +2128,7 @@ int launch_wide_inst(const GemmDev& d, int grid, hipStream_t st) {
 int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
   if (a.w8 || a.rb != 0 || a.batch > 1 || a.M % TileW::BM || a.N % TileW::BN || a.K < 2 * 64 || a.K % 64 || !d.wide8) return -1;
   if ((long long)a.M * a.lda * 2 >= (1LL << 32) || (long long)a.N * a.ldw * 2 >= (1LL << 32)) return -1;
-  if (a.mul || a.res || a.out32 || a.hm_D) return -1;
+  if (a.mul || a.res || a.out32 || a.hm_D || a.split_n) return -1;
   int epi = 0;
   if (!a.resT && !a.ssq_out) epi = 1;
   else if (a.resT && !a.rs_ssq && a.act == ACT_NONE) epi = 4;
@@ -2136,6 +2151,64 @@ int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
     case ACT_RELU * 8 + 1: return launch_wide_inst<ACT_RELU, 1>(d, grid, st);
     case ACT_QUICKGELU * 8 + 1: return launch_wide_inst<ACT_QUICKGELU, 1>(d, grid, st);
     case ACT_NONE * 8 + 4: return launch_wide_inst<ACT_NONE, 4>(d, grid, st);
+    default: return -1;
+  }
+}
+
+template <int ACT, int EPI>
+int launch_q4_inst(const GemmDev& d, int grid, hipStream_t st) {
+  static PerDeviceOnce attr;   // per instantiation, per device
+  {
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<ACT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Q4::SMEM_BYTES); });
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL((gemm_q4_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(Q4::THREADS), Q4::SMEM_BYTES, st, d);
+  return (int)hipGetLastError();
+}
+
+// 256 x 384 four-wave kernel (option gemm_q4): returns -1 when the problem does not fit it (caller falls back to the 256x256 kernels)
+int launch_q4(GemmDev d, const GemmArgs& a, hipStream_t st) {
+  if (a.w8 || a.a8 || a.rb != 0 || a.batch > 1 || a.M % Q4::BM || a.N % Q4::BN || a.K < 128 || a.K % 128 || !d.wide8) return -1;
+  if ((long long)a.M * a.lda * 2 >= (1LL << 32) || (long long)a.N * a.ldw * 2 >= (1LL << 32)) return -1;
+  if (a.mul || a.res || a.out32 || a.out8 || a.split_n || a.pair32 || a.rs_ssq || a.sum_out) return -1;
+  int epi = 0;
+  if (!a.resT && !a.ssq_out) epi = a.hm_D ? 5 : 1;
+  else if (a.resT && a.act == ACT_NONE && !a.hm_D) epi = 4;
+  if (!epi) return -1;
+  if (epi == 5 && a.act != ACT_NONE) return -1;
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cu = n / 8 * 8;
+    if (kLab) { const int lim = env_int("VIMA_GEMM_LAB_CUS", 0); if (lim >= 8 && lim < g_num_cu) g_num_cu = lim / 8 * 8; }
+  }
+  d.mtiles = d.M / Q4::BM;
+  d.ntiles = d.N / Q4::BN;
+  if ((long long)d.mtiles * d.ntiles < 128) return -1;
+  d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
+  d.raster = 0; d.epi_lds = 1; d.flat = 0;
+  d.ngroup = d.ntiles;
+  {   // n-groups whose W panels stay in an XCD's L2 (see launch_pp)
+    static int kb = -1;
+    if (kb < 0) kb = env_int("VIMA_GEMM_NGROUP_KB", 2560);
+    const long long panel = (long long)Q4::BN * a.K * 2;
+    if (kb > 0 && a.K <= 1536 && (long long)d.ntiles * panel > (long long)kb * 1024) {
+      int ng = (int)((long long)kb * 1024 / panel);
+      if (ng < 1) ng = 1;
+      const int groups = (d.ntiles + ng - 1) / ng;
+      d.ngroup = (d.ntiles + groups - 1) / groups;
+    }
+  }
+  d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
+  const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
+  if (epi == 5) return launch_q4_inst<ACT_NONE, 5>(d, grid, st);
+  switch (a.act * 8 + epi) {
+    case ACT_NONE * 8 + 1: return launch_q4_inst<ACT_NONE, 1>(d, grid, st);
+    case ACT_RELU * 8 + 1: return launch_q4_inst<ACT_RELU, 1>(d, grid, st);
+    case ACT_QUICKGELU * 8 + 1: return launch_q4_inst<ACT_QUICKGELU, 1>(d, grid, st);
+    case ACT_NONE * 8 + 4: return launch_q4_inst<ACT_NONE, 4>(d, grid, st);
     default: return -1;
   }
 }
@@ -2379,10 +2452,6 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   d.rb = a.rb; d.s_hi = a.s_hi; d.s_lo = a.s_lo; d.ro = a.ro;
   d.hm_D = a.hm_D; d.hm_L = a.hm_L;
   d.outT_lo = a.outT_lo; d.ldT_lo = a.ldT_lo; d.split_n = a.split_n;
-  if (a.split_n && (sizeof(T) != 2 || !a.outT || !a.outT_lo || a.out32 || a.out8 || a.mul || a.res || a.resT || a.ssq_out || a.hm_D || a.pair32 || a.W2 || a.grp_col ||
-                    a.batch > 1 || a.split_n <= 0 || a.split_n >= a.N || a.split_n % 128 != 0 || a.N % 8 != 0 || a.ldT_lo % 8 != 0 || !aligned_to(a.outT_lo, 16) ||
-                    a.w8 || a.a8 || gemm_splitk(a.tune)))
-    return (int)hipErrorInvalidValue;
   if (a.hm_D && (sizeof(T) != 2 || !a.outT || a.out32 || a.mul || a.res || a.resT || a.out8 || a.ssq_out || a.rb > 0 || a.batch > 1 || a.grp_col || a.W2 ||
                  !gemm_headmajor_ok(a.tune, a.M, a.N, a.K, a.lda, a.ldw, a.hm_D, a.hm_L, a.a8)))
     return (int)hipErrorInvalidValue;
@@ -2405,6 +2474,12 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
   if (a.out32) v = v && aligned_to(a.out32, 16) && (a.ld32 % 4 == 0) && (a.bs32 % 4 == 0);
   if (a.outT) v = v && aligned_to(a.outT, 4 * es) && (a.ldT % 4 == 0) && (a.bsT % 4 == 0);
   if (a.w8 && !v) return (int)hipErrorInvalidValue;   // fp8 weights need the vector epilogue (16-byte aligned outputs)
+  // column-split output: the VECTOR epilogues of the one-tile-per-workgroup / resident / skinny kernels only (the scalar epilogue and the persistent
+  // kernels' epilogues do not know split_n: a launch that could reach them is refused, never mis-stored)
+  if (a.split_n && (sizeof(T) != 2 || !v || !a.outT || !a.outT_lo || a.out32 || a.out8 || a.mul || a.res || a.resT || a.ssq_out || a.hm_D || a.pair32 || a.W2 || a.grp_col ||
+                    a.batch > 1 || a.split_n <= 0 || a.split_n >= a.N || a.split_n % 128 != 0 || a.N % 8 != 0 || a.ldT_lo % 8 != 0 || !aligned_to(a.outT_lo, 16) ||
+                    a.w8 || a.a8 || gemm_splitk(a.tune)))
+    return (int)hipErrorInvalidValue;
   d.wide8 = 0;
   if constexpr (sizeof(T) == 2) {
     d.wide8 = (v && (a.outT || a.out8) && !a.out32 && a.N % 8 == 0 && a.ldT % 8 == 0 && a.bsT % 8 == 0 && aligned_to(a.outT, 16) &&
@@ -2446,9 +2521,14 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     const long long mt = (a.M + 255) / 256, nt = (a.N + 255) / 256;
     const double waste = (double)(mt * 256) * (double)(nt * 256) / ((double)a.M * (double)a.N);
     bool large = v && (mt * nt * (a.batch > 0 ? a.batch : 1) >= 160) && waste < 1.15;   // measured: 192 tiles of 256x256 beat 768 of 128x128 by 10-28 %
-    if (gemm_tile(a.tune) == 1 || a.split_n) large = false;   // (the column-split output exists in the one-tile-per-workgroup / resident / skinny epilogues)
+    if (gemm_tile(a.tune) == 1) large = false;
     if (gemm_tile(a.tune) >= 2 && gemm_tile(a.tune) < 7) large = v;
     if (gemm_tile(a.tune) >= 7) large = false;
+    if (a.split_n) large = false;   // after every override: the column-split output exists in the one-tile-per-workgroup / resident / skinny epilogues only
+    if (large && gemm_q4(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {
+      const int e = launch_q4(d, a, st);
+      if (e >= 0) { if (a.kernel_id) *a.kernel_id = 19000 + (a.act + 1) * 10 + (a.hm_D ? 5 : (a.resT ? 4 : 1)); return e; }
+    }
     if (large && gemm_wide(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {
       const int e = launch_wide(d, a, st);
       if (e >= 0) { if (a.kernel_id) *a.kernel_id = 3000 + (a.act + 1) * 10 + (a.resT ? 4 : 1); return e; }

@@ -1650,6 +1650,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "gemm_persist") h->tune.gemm_persist = (int)value;
   else if (k == "gemm_splitk") h->tune.gemm_splitk = (int)value;
   else if (k == "gemm_wide") h->tune.gemm_wide = (int)value;
+  else if (k == "gemm_q4") h->tune.gemm_q4 = (int)value;
   else if (k == "gemm_pp") h->tune.gemm_pp = (int)value;
   else if (k == "gemm_small") h->tune.gemm_small = (int)value;
   else if (k == "gemm_resident") h->tune.gemm_resident = (int)value;
