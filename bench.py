@@ -167,23 +167,28 @@ def cached_state_dict(syn, cfg, rank, world, dist):
     (memory-mapped), rank 0 removes it -- instead of N concurrent host-side builds. Returns (state dict, how it was obtained)."""
     if world == 1:
         return syn.make_state_dict(cfg, 0), "built in process"
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"vima_sd_{cfg.embed_dim}_{cfg.xf_n_layers}_{cfg.xattn_n_positions}_{os.environ.get('MASTER_PORT', '0')}.pt")
+    # rank 0 creates a PRIVATE directory (mkdtemp: mode 0700, unpredictable name) and tells the others where it is; the ranks of one node share its
+    # file system (bench.py is a single-node tool: --nnodes=1)
+    import tempfile
+    holder = [None]
     sd = None
     t0 = time.perf_counter()
     if rank == 0:
+        holder[0] = os.path.join(tempfile.mkdtemp(prefix="vima_sd_"), "state_dict.pt")
         sd = syn.make_state_dict(cfg, 0)
-        torch.save(sd, path + ".tmp")
-        os.replace(path + ".tmp", path)
-    dist.barrier()
+        torch.save(sd, holder[0])
+    dist.broadcast_object_list(holder, src=0)
+    path = holder[0]
     if rank != 0:
         try:
             sd = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
-        except TypeError:       # torch without the mmap argument
-            sd = torch.load(path, map_location="cpu")
+        except TypeError:       # torch without the mmap argument: still tensors only, never arbitrary pickles
+            sd = torch.load(path, map_location="cpu", weights_only=True)
     dist.barrier()
     if rank == 0:
         try:
             os.remove(path)
+            os.rmdir(os.path.dirname(path))
         except OSError:
             pass
     return sd, f"rank 0 built it once ({time.perf_counter() - t0:.1f} s incl. the file), ranks 1..{world - 1} read {os.path.basename(path)}"
@@ -466,8 +471,71 @@ def extras(args, pol, syn, cfg, prompts, obs, past, sync, dev, rank, n_seg, Q, B
     return warm_ms, inc_ms, secondary
 
 
+def bench_baseline_policy(args):
+    """`--policy gpt|gato|flamingo`: ONE measured line for a baseline policy (reference:
+    vima/policy/vima_gpt_policy.py:118-187, vima_gato_policy.py:115-188, vima_flamingo_policy.py:121-227) at the VIMA-200M transformer size
+    (embed_dim 768, 11 layers, 12 heads), batch `--batch`, a prompt of 8 segments of (`--words` words + 1 RGB frame pair) and T = `--steps-history`
+    observation steps: the COLD step (prompt encoding + observation encoding + decoder + action head), timed like the headline, with the
+    library's own per-class split (HIP events on the launch stream). Not the headline metric: `config.workload` names it."""
+    from vima_testing import synthetic as syn
+    from vima_amd.baselines import build_baseline
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    kind = args.policy
+    cfg = syn.BaselineConfig(kind, 768, 11, 12, xattn_n_heads=12 if kind == "flamingo" else 0)
+    sd = syn.make_baseline_state_dict(cfg, 0)
+    pol = build_baseline(cfg, precision=args.precision, device=dev)
+    pol.load_state_dict(sd, strict=True)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        pol.set_option(k, int(v))
+    B, T, n_seg = args.batch, args.steps_history, 8
+    prompts = syn.to_device(syn.make_rgb_prompt(B, n_segments=n_seg, words_per_segment=args.words, seed=1236), dev)
+    obs = syn.to_device(syn.make_rgb_obs(T, B, seed=1336), dev)
+    past = syn.to_device(syn.make_actions(T - 1, B, seed=1436), dev) if T > 1 else None
+
+    def step():
+        ptok, pmask = pol.forward_prompt_assembly(prompts)
+        otok = pol.forward_obs_token(obs)
+        atok = pol.forward_action_token(past) if past is not None else None
+        pred = pol.forward(otok, atok, ptok, pmask)
+        return pol.action_logits(pred[-1]), ptok.shape[0]
+
+    for _ in range(max(args.warmup, 1)):
+        logits, Lp = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and tuple(logits.shape) == (B, 700)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    pol.prof_enable(True)
+    pol.set_option("dual_stream", 0)
+    step()
+    torch.cuda.synchronize()
+    prof = pol.prof_read_ex()
+    pol.prof_enable(False)
+    tot_fl = sum(prof[k]["flops"] for k in prof)
+    split = {k: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0}
+             for k, v in prof.items()}
+    print(json.dumps({
+        "metric": f"policy-forward steps/sec, {kind} baseline policy (VIMA-200M transformer size), batch {B}", "value": round(1e3 / ms, 4), "unit": "steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"{kind} baseline policy: embed_dim 768, 11 layers, 12 heads; batch {B}; prompt of {n_seg} x ({args.words} words + 1 RGB frame pair) = "
+                               f"{Lp} tokens; T = {T} observation steps ({cfg.obs_tokens} tokens each); COLD step (prompt + observation encoding, decoder, "
+                               f"action head); random-init weights", "policy": kind, "prompt_tokens": int(Lp), "obs_tokens_per_step": cfg.obs_tokens},
+        "class_split_dual_stream_off": split,
+        "roofline": {"bound": "mfma", "achieved": round(tot_fl / (ms * 1e-3) / 1e12, 1), "peak": BF16_PEAK_TFLOPS if args.precision != "fp32" else FP32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(tot_fl / (ms * 1e-3) / 1e12 / (BF16_PEAK_TFLOPS if args.precision != "fp32" else FP32_PEAK_TFLOPS), 4),
+                     "traffic": None, "note": "whole step: the launch log's executed FLOPs / wall time"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--policy", default="vima", choices=["vima", "gpt", "gato", "flamingo"], help="vima: the headline workload (default); gpt / gato / flamingo: "
+                    "one measured line for that BASELINE policy (1 GPU, its own metric)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -495,6 +563,10 @@ def main():
     ap.add_argument("--no-side-configs", action="store_true", help="skip the other BASELINE.json configurations (VIMA-20M batch 32, Lp = 1024 in bf16 "
                     "and fp8, T = 8) that the default run reports under config.secondary_cold")
     args = ap.parse_args()
+    if args.policy != "vima":
+        if args.gpus != 1 or os.environ.get("WORLD_SIZE", "1") != "1":
+            sys.exit("bench.py --policy gpt|gato|flamingo is a single-GPU line")
+        return bench_baseline_policy(args)
 
     # ---- N ranks: `--gpus N` without a torchrun environment re-launches this script under torch.distributed.run with one
     # rank per GPU; it never silently measures fewer GPUs than asked for.
@@ -502,6 +574,8 @@ def main():
     # agreement / max-over-ranks path below can be EXECUTED on a one-GPU box; the printed line is marked and is not a measurement
     shared_gpu = os.environ.get("VIMA_BENCH_SHARED_GPU") == "1"
     dry = os.environ.get("VIMA_BENCH_DRY") == "1"
+    if args.dry_ranks == 1 or args.dry_ranks < 0:
+        sys.exit("bench.py: --dry-ranks needs at least 2 ranks (it rehearses the N > 1 host path)")
     if args.dry_ranks and "WORLD_SIZE" not in os.environ:
         import socket
         import subprocess
@@ -690,6 +764,11 @@ def main():
     collective_info = None
     if rccl_log and rank == 0:
         collective_info = rccl_summary(rccl_log)
+    if rccl_log:
+        try:
+            os.remove(rccl_log)          # summarised above: do not leave one log file per rank and run in /tmp
+        except OSError:
+            pass
     if dry:
         # every rank holds every rank's rows, in rank order
         want = (torch.arange(B, dtype=torch.float32)[None, :] + 1000.0 * torch.arange(world, dtype=torch.float32)[:, None]).reshape(-1)

@@ -65,7 +65,7 @@ def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
     not track; the destination VGPRs count as written at the asm statement, so the compiler could legally read, copy or reuse
     them before the data lands (guide: cdna_hip_programming.md 5.7 item 1). This audits the generated ISA: between an asm
     `global_load_dwordx4` and the counted `s_waitcnt` that covers it, no other instruction may name those registers. Loads
-    are issued one slab ahead, so at every wait the batch issued right before it stays in flight and all older ones retire."""
+    are issued up to three slabs ahead; the count of every wait says how many of the youngest stay in flight."""
     src, _ = _compile("gemm.hip")
 
     def regs(tok):
@@ -97,9 +97,14 @@ def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
                 since_wait += 1
                 continue
             if in_asm and toks[0] == "s_waitcnt":
-                # VMEM retires in order: everything but the youngest `nit` loads (the next slab's, issued right before this
-                # wait) has landed; on the last slab nothing was issued since the previous wait and everything has landed
-                pending = pending[-nit:] if since_wait else []
+                # VMEM loads retire in order: a counted wait `vmcnt(n)` leaves the n youngest loads in flight (the slabs prefetched
+                # ahead: up to three of them since round 6) and retires every older one
+                mm = re.search(r"vmcnt\((\d+)\)", t)
+                if mm:
+                    n = int(mm.group(1))
+                    if pending:     # an epilogue wait (the main loop's own counted waits find nothing of the epilogue pending)
+                        assert n % nit == 0 and n <= 3 * nit, (m.group(1), t)
+                    pending = pending[-n:] if n else []
                 since_wait = 0
                 continue
             if not in_asm and pending:
@@ -113,3 +118,34 @@ def test_prefetched_epilogue_registers_are_not_touched_before_their_wait():
         assert loads in (16, 32, 64), (m.group(1), loads)
         checked += 1
     assert checked >= 9, checked
+
+
+def test_q4_kernel_stream_is_what_was_written():
+    """gemm_q4_kernel (256x384, one wave per SIMD) owns its registers by hand: MFMAs and fragment reads are inline asm with tied operands, the
+    lgkmcnt waits in front of the MFMAs are counted on the assumption that ONLY its own LDS reads are in flight, and its LDS-DMA helper writes M0
+    without saving it. The ISA must therefore show, for every instantiation: no scratch; 256 AGPRs; and between the first and the last MFMA of the
+    K loop no scalar load (SMEM returns out of order and shares lgkmcnt), no accumulator shuffle between the register files (v_accvgpr_*: the
+    compiler cannot see the MFMA's latency), no spill traffic, no branch; M0 is named by the LDS-DMA helper only."""
+    src, _ = _compile("gemm.hip")
+    res = _usage("gemm.hip")
+    q4 = {k: v for k, v in res.items() if "gemm_q4_kernel" in k}
+    assert len(q4) >= 5, sorted(q4)
+    for k, v in q4.items():
+        assert v.get("ScratchSize", 0) == 0, (k, v)
+        assert v.get("AGPRs", 0) == 256 and v.get("VGPRs", 0) <= 256, (k, v)
+    checked = 0
+    for m in re.finditer(r"^(_ZN4vima\S*gemm_q4_kernel\S*):", src, flags=re.M):
+        body = src[m.end():src.index(".Lfunc_end", m.end())].split("\n")      # (the kernel has an early exit: several s_endpgm)
+        code = [ln.strip() for ln in body if ln.strip() and ln.strip()[0] not in ";."]
+        idx = [i for i, ln in enumerate(code) if ln.startswith("v_mfma_f32_32x32x16_bf16")]
+        assert len(idx) == 192, (m.group(1), len(idx))                 # 8 phases x 24: ONE loop body
+        loop = code[idx[0]:idx[-1] + 1]
+        bad = [ln for ln in loop if re.match(r"(s_load|s_buffer_load|v_accvgpr|scratch_|s_cbranch|v_readlane|v_writelane)", ln)]
+        assert not bad, (m.group(1), bad[:4])
+        assert sum(ln.startswith("ds_read_b128") for ln in loop) == 94, m.group(1)          # 2 K-tiles x 48 rolling reads (the last two follow the last MFMA)
+        assert sum(ln.startswith("global_load_lds_dwordx4") for ln in loop) == 40, m.group(1)   # 2 K-tiles x 20 pieces
+        assert sum(ln.startswith("s_barrier") for ln in loop) == 7, m.group(1)             # 8 phases (the last one's barrier follows the last MFMA)
+        m0 = [ln for ln in code if re.search(r"\bm0\b", ln)]
+        assert m0 and all(ln.startswith("s_mov_b32 m0, s") for ln in m0), (m.group(1), [ln for ln in m0 if not ln.startswith("s_mov_b32 m0, s")][:3])
+        checked += 1
+    assert checked >= 5, checked

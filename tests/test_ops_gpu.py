@@ -682,3 +682,47 @@ def test_linear_wide_tile_is_bit_identical(M, N, K, act, stream):
         pol.set_option("gemm_wide", 0)
         pol.set_option("op_bf16_out", 0)
         pol.set_option("op_stream_T", 0)
+
+
+@pytest.mark.parametrize("M,N,K,act,stream", [(16384, 768, 768, 0, 1), (16384, 768, 768, 0, 0), (16384, 2304, 128, 0, 0), (16384, 3072, 768, 3, 0),
+                                              (24576, 1536, 3072, 1, 0), (32768, 768, 3072, 0, 1), (8192, 6144, 256, 0, 0)])
+def test_linear_q4_tile_is_bit_identical(M, N, K, act, stream):
+    """gemm_q4_kernel (option gemm_q4: 256x384 tile on four waves, one per SIMD; Gray-code quadrant phases, rolling in-place fragment reloads,
+    inline-asm MFMAs with 128 of the 384 accumulator registers in VGPRs) accumulates K in the same order with the same MFMA as every other tile
+    shape: identical bits to the 256x256 ping-pong kernel (bias, activation, bf16 residual stream with its RMS partials), and the usual
+    agreement with torch. The shapes cover one to sixteen tiles per workgroup and 2 .. 48 K-tiles."""
+    pol = bare_policy("bf16")
+    pol.set_option("op_bf16_out", 1)
+    pol.set_option("op_stream_T", stream)
+    try:
+        g = torch.Generator().manual_seed(M + N + K + 1)
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * K ** -0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g) * 3.0 if stream else None
+        d = [None if t is None else t.cuda() for t in (A, W, b, None, r)]
+        outs, kinds = [], []
+        for q4 in (0, 1):
+            pol.set_option("gemm_q4", q4)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            pol.prof_enable(True)
+            _lib.check(pol._lib.vima_op_linear(pol._handle, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), M, N, K, act,
+                                               ptr(out), pol._stream()))
+            torch.cuda.synchronize()
+            kinds.append([l["kernel"] for l in pol.prof_read_gemm_launches()])
+            pol.prof_enable(False)
+            outs.append(out)
+        assert any("gemm_q4_kernel" in k for k in kinds[1]) and not any("gemm_q4_kernel" in k for k in kinds[0]), kinds
+        assert torch.isfinite(outs[1]).all()
+        assert torch.equal(outs[0], outs[1])
+        ref = bf(A) @ bf(W).T + b
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 3:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        ref = bf(ref + bf(r)) if stream else bf(ref)
+        assert max_rel(outs[1], ref) < 6e-3, max_rel(outs[1], ref)
+    finally:
+        pol.set_option("gemm_q4", 0)
+        pol.set_option("op_bf16_out", 0)
+        pol.set_option("op_stream_T", 0)

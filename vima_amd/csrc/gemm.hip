@@ -822,7 +822,17 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   if (EPI == 2) { auxp = reinterpret_cast<const char*>(mul + (long long)mrow0 * p.ldmul + ncol0); aux_ld = (long long)p.ldmul * 2; }
   if (EPI == 3) { auxp = reinterpret_cast<const char*>(res + (long long)mrow0 * p.ldres + ncol0); aux_ld = (long long)p.ldres * 4; }
   if (EPI == 4) { auxp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.resT) + (long long)mrow0 * p.ldresT + ncol0); aux_ld = (long long)p.ldresT * 2; }
-  f32x4_t aux[2][NIT];
+  // prefetch distance of the per-row operand in slabs. One slab ahead (rounds 2-5) the loads of slab sl are issued one slab period (~2 k clocks of a wave that
+  // shares its SIMD) before their wait -- less than the latency of a load that misses L2 under load (the bf16 residual stream is 200 MB: HBM), and the
+  // stream epilogue ran 17 k clocks against 3.5 k for the bf16-output one. The fragments are dead here, so the extra buffers cost no registers.
+  // (three slabs ahead where a slab's operand is 2 registers per lane and row group -- the bf16 stream and the GEGLU gate of the 8-wave kernels; the fp32
+  // residual (4 row groups x 4 registers per slab) and gemm_q4_kernel (128 of its accumulators are VGPRs) keep one: deeper they spill)
+#ifdef VIMA_LAB_AUXD
+  constexpr int AUXD = VIMA_LAB_AUXD;
+#else
+  constexpr int AUXD = (NIT == 2 && NI == 2) ? 3 : 1;
+#endif
+  f32x4_t aux[AUXD + 1][NIT];
   auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {
     const int mi = sl / NI, ni = sl % NI;
 #pragma unroll
@@ -831,7 +841,10 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[it]) : "v"(q) : "memory");
     }
   };
-  if (aux_on) issue_aux(0, aux[0]);
+  if (aux_on) {
+#pragma unroll
+    for (int d = 0; d < AUXD && d < MI * NI; ++d) issue_aux(d, aux[d]);
+  }
   // Epilogues with a per-row operand (AUX) hold a slab's finished values in registers and issue its STORES one slab late, behind the next slab's
   // operand wait -- see the note at that wait. h_*: the held slab (which members are live depends on EPI; the others are dead code).
   uint4 h_o[NIT];
@@ -882,15 +895,12 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
       // clobber keeps hipcc from moving the C++ stores across the wait.
       if (AUX) {
        if (aux_on) {
-        if (sl + 1 < NSLAB) issue_aux(sl + 1, aux[(sl + 1) & 1]);
-        f32x4_t(&a)[NIT] = aux[sl & 1];
-        if (sl + 1 < NSLAB) {
-          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "i"(NIT) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(NIT) : "memory");
-        } else {   // last slab: no younger loads
-          if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]) : : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : : "memory");
-        }
+        if (sl + AUXD < NSLAB) issue_aux(sl + AUXD, aux[(sl + AUXD) % (AUXD + 1)]);
+        f32x4_t(&a)[NIT] = aux[sl % (AUXD + 1)];
+        // younger LOADS at this point: those of slabs sl + 1 .. min(sl + AUXD, NSLAB - 1)
+        const int younger = (NSLAB - 1 - sl < AUXD ? NSLAB - 1 - sl : AUXD) * NIT;   // compile-time after unrolling
+        if constexpr (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(younger) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(younger) : "memory");
        }
         if (sl > 0) emit_stores(sl - 1);
       }
@@ -910,7 +920,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           if (act != ACT_NONE) { v[j].x = apply_act_t<bf16_t>(v[j].x, act); v[j].y = apply_act_t<bf16_t>(v[j].y, act); v[j].z = apply_act_t<bf16_t>(v[j].z, act); v[j].w = apply_act_t<bf16_t>(v[j].w, act); }
         }
         if constexpr (EPI == 2) {        // x gate: 8 bf16 values
-          const f32x4_t g = aux[sl & 1][it];
+          const f32x4_t g = aux[sl % (AUXD + 1)][it];
           const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
           v[0].x *= __uint_as_float(g0 << 16); v[0].y *= __uint_as_float(g0 & 0xffff0000u);
           v[0].z *= __uint_as_float(g1 << 16); v[0].w *= __uint_as_float(g1 & 0xffff0000u);
@@ -918,7 +928,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
           v[1].z *= __uint_as_float(g3 << 16); v[1].w *= __uint_as_float(g3 & 0xffff0000u);
         }
         if constexpr (EPI == 4) {        // + residual carried in bf16: 8 values
-          const f32x4_t g = aux[sl & 1][it];
+          const f32x4_t g = aux[sl % (AUXD + 1)][it];
           const uint32_t g0 = __float_as_uint(g[0]), g1 = __float_as_uint(g[1]), g2 = __float_as_uint(g[2]), g3 = __float_as_uint(g[3]);
           v[0].x += __uint_as_float(g0 << 16); v[0].y += __uint_as_float(g0 & 0xffff0000u);
           v[0].z += __uint_as_float(g1 << 16); v[0].w += __uint_as_float(g1 & 0xffff0000u);
@@ -927,7 +937,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
         }
         if constexpr (EPI == 3) {        // + residual: 4 fp32 values
           if (aux_on) {
-            const f32x4_t r4 = aux[sl & 1][it];
+            const f32x4_t r4 = aux[sl % (AUXD + 1)][it];
             v[0].x += r4[0]; v[0].y += r4[1]; v[0].z += r4[2]; v[0].w += r4[3];
           }
         }
