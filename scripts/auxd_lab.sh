@@ -1,4 +1,5 @@
 #!/bin/bash
+# variant binaries: for d in 1 2 3 4; do bash scripts/micro/build_gemm_lab.sh r06 auxd$d -DVIMA_LAB_AUXD=$d; done
 # stream epilogue (EPI 4) / gate epilogue (EPI 2): prefetch distance of the per-row operand, 1 (rounds 2-5) .. 4 slabs; separate binaries, rounds interleaved by the loop below
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 L=$R/scripts/micro/gemm_lab

@@ -1,4 +1,5 @@
 #!/bin/bash
+# variant binaries: bash scripts/micro/build_gemm_lab.sh r06 ppstamps -DVIMA_PP_PHASE_STAMPS; for v in FULLLINE NOSTORE1; do bash scripts/micro/build_gemm_lab.sh r06 $v -DVIMA_LAB_$v -DVIMA_PP_PHASE_STAMPS; done
 # pp epilogue store shape: shipped (64-byte half lines per row and instruction) vs timing-only full 128-byte lines vs no stores; phase stamps
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 L=$R/scripts/micro/gemm_lab

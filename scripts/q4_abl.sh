@@ -1,4 +1,5 @@
 #!/bin/bash
+# variant binaries: for v in NOWAIT NOBAR NODMA NOREAD KT_STAMPS; do bash scripts/micro/build_gemm_lab.sh r06 q4$v -DVIMA_Q4_$v; done; bash scripts/micro/build_gemm_lab.sh r06 ppstamps -DVIMA_PP_PHASE_STAMPS
 # gemm_q4_kernel: difference map against gemm_pp_kernel on small problems + timing-only ablations of its main loop (lab builds -DVIMA_Q4_NOWAIT / _NOBAR / _NODMA / _NOREAD)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 L=$R/scripts/micro/gemm_lab

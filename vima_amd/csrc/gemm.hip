@@ -827,11 +827,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   // stream epilogue ran 17 k clocks against 3.5 k for the bf16-output one. The fragments are dead here, so the extra buffers cost no registers.
   // (three slabs ahead where a slab's operand is 2 registers per lane and row group -- the bf16 stream and the GEGLU gate of the 8-wave kernels; the fp32
   // residual (4 row groups x 4 registers per slab) and gemm_q4_kernel (128 of its accumulators are VGPRs) keep one: deeper they spill)
-#ifdef VIMA_LAB_AUXD
-  constexpr int AUXD = VIMA_LAB_AUXD;
-#else
   constexpr int AUXD = (NIT == 2 && NI == 2) ? 3 : 1;
-#endif
   f32x4_t aux[AUXD + 1][NIT];
   auto issue_aux = [&](int sl, f32x4_t (&dst)[NIT]) {
     const int mi = sl / NI, ni = sl % NI;
@@ -952,15 +948,7 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
             const long long o_ = bq * (long long)p.hm_L * (p.N - p.hm_D) + m * p.hm_D + ((long long)(n >> lg) * p.hm_L << lg) + (n & (p.hm_D - 1));
             *reinterpret_cast<uint4*>(outT + o_) = o;
           } else
-#if defined(VIMA_LAB_FULLLINE)   // timing-only (wrong values): every store instruction writes FULL 128-byte lines -- 8 lanes per row x 64 columns -- instead of 64-byte halves
-          { const long long mf = m0 + wm * (MI * 32) + mi * 32 + (ni & 1) * 16 + it * 8 + (elane >> 3);
-            const int nf = n0 + wn * (NI * 32) + (ni & ~1) * 32 + (elane & 7) * 8;
-            *reinterpret_cast<uint4*>(outT + mf * p.ldT + nf) = o; }
-#elif defined(VIMA_LAB_NOSTORE1)   // timing-only: no output stores (EPI 1)
-          asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
-#else
           if (!O8 || outT) *reinterpret_cast<uint4*>(outT + m * p.ldT + n) = o;
-#endif
           }
           if (O8 && p.out8) {   // fp8 e4m3 copy for an fp8 consumer GEMM: e4m3(v * out8_inv), saturating
             const float q = p.out8_inv;
