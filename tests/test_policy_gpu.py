@@ -1006,3 +1006,35 @@ def test_batch32_cold_step_200m_against_live_oracle():
           f"argmax agreement {agree}/{total}, worst reference gap at a flip {gap:.3e}")
     assert err < 1e-3, err
     assert gap <= 2 * err + 1e-7
+
+
+def test_q4_gemm_tile_in_the_headline_batch_is_bit_identical():
+    """Round 6: with option gemm_q4 the large bf16 GEMMs whose N is a multiple of 384 (ViT in_proj / fc / out_proj / c_proj, T5 o / wo, the decoder's
+    head-major prompt K / V projection) run on gemm_q4_kernel (256x384 tile, four waves, inline-asm MFMAs with accumulators in both register files).
+    The headline batch (VIMA-200M, B = 256, Lp = 512, bench.py's seeds) must come out BIT-IDENTICAL to the default kernels -- every tile shape
+    accumulates K in the same order -- and the launch log must show that the kernel really ran in every epilogue form it has."""
+    cfg = syn.config("200M", xattn_n_positions=512)
+    sd = syn.make_state_dict(cfg, 0)
+    B = 256
+    prompts = syn.to_device(syn.make_prompt(B, n_segments=32, words_per_segment=8, q_per_view=4, seed=1236), DEV)
+    obs = syn.to_device(syn.make_obs(1, B, 4, seed=1336), DEV)
+    pol = loaded_policy(cfg, sd, "bf16")
+
+    def step():
+        ptok, pmask = pol.forward_prompt_assembly(prompts)
+        otok, omask = pol.forward_obs_token(obs)
+        return ptok, otok, pol.action_logits(pol.forward(otok, omask, None, ptok, pmask)[-1])
+
+    ref = step()
+    pol.set_option("gemm_q4", 1)
+    pol.prof_enable(True)
+    got = step()
+    torch.cuda.synchronize()
+    kinds = sorted(set(l["kernel"] for l in pol.prof_read_gemm_launches() if "gemm_q4_kernel" in l["kernel"]))
+    pol.prof_enable(False)
+    pol.set_option("gemm_q4", 0)
+    print(f"[q4] kernels in the headline step: {kinds}")
+    assert any(k.endswith("<0, 4>") for k in kinds) and any(k.endswith("<0, 5>") for k in kinds) and any(k.endswith("<0, 1>") for k in kinds) \
+        and any(k.endswith("<3, 1>") for k in kinds), kinds
+    for a, b, what in zip(ref, got, ("prompt tokens", "obs tokens", "logits")):
+        assert torch.equal(a, b), what
