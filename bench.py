@@ -177,7 +177,7 @@ def cached_state_dict(syn, cfg, rank, world, dist):
         holder[0] = os.path.join(tempfile.mkdtemp(prefix="vima_sd_"), "state_dict.pt")
         sd = syn.make_state_dict(cfg, 0)
         torch.save(sd, holder[0])
-    dist.broadcast_object_list(holder, src=0)
+    dist.broadcast_object_list(holder, src=0, device=(torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else None))
     path = holder[0]
     if rank != 0:
         try:
