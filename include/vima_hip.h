@@ -250,8 +250,9 @@ int vima_t5_bucket(int relative_position);
  *                            "gemm_persist" [1] large bf16 GEMMs on the persistent 256x256 kernels
  *                            "gemm_pp"      [1] ping-pong (8-phase) main loop of the persistent kernel (0: the round-2 loop)
  *                            "gemm_wide"    [0] 256x384 persistent tile where N % 384 == 0
- *                            "gemm_q4"      [0] 256x384 persistent tile on FOUR waves (one per SIMD, 384 accumulator registers each: gemm_q4_kernel)
- *                                               where M % 256 == 0, N % 384 == 0, K % 128 == 0 (bf16-output / bf16-stream / head-major epilogues)
+ *                            "gemm_q4"      [0] gemm_q4_kernel, FOUR waves (one per SIMD) with a 384-column tile, where N % 384 == 0, K % 128 == 0 (bf16-output /
+ *                                               bf16-stream / head-major epilogues): 1 its 256x384 tile wherever it fits, 2 its 128x384 tile wherever it fits,
+ *                                               3 the 128x384 tile where it needs fewer rounds of the chip than the 256x256 tiling (batch 32), 0 off
  *                            "gemm_small"   [1] 64x64 / 32x64 tiles for grids that would leave most CUs idle
  *                            "gemm_resident" [1] underfilled grids on gemm_resident_kernel ((almost) the whole K extent in flight, one
  *                                               barrier per chunk of K-slices; bit-identical to the ring tiles), 0: the 4-deep ring tiles

@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
       else if (nm == "fp8") v.t.gemm_pp = 1;     // fp8 e4m3 A and W, v_mfma_scale_f32_32x32x64_f8f6f4 (own operands / reference)
       else if (nm == "wide") v.t.gemm_wide = 1;
       else if (nm == "q4") { v.t.gemm_pp = 1; v.t.gemm_q4 = 1; }   // 256x384, four waves (one per SIMD)
+      else if (nm == "q4h") { v.t.gemm_pp = 1; v.t.gemm_q4 = 2; }  // 128x384, four waves
       else { printf("unknown variant %s\n", nm.c_str()); return 1; }
       vars.push_back(v);
     }
@@ -183,7 +184,7 @@ int main(int argc, char** argv) {
         for (int i = 16; i < 14 + nit; ++i) printf(" %.0f", acc[i] / c2);
         printf("\n");
       }
-      if (vars[vi].name == "q4" && getenv("KTSTAMPS")) {   // -DVIMA_Q4_KT_STAMPS builds: mean clocks of each K-tile of a tile (first 32), from the start of its main loop
+      if ((vars[vi].name == "q4" || vars[vi].name == "q4h") && getenv("KTSTAMPS")) {   // -DVIMA_Q4_KT_STAMPS builds: mean clocks of each K-tile of a tile (first 32), from the start of its main loop
         const int nkt = std::min(K / 64, 32);
         const int nb4 = ((M + 255) / 256 + 7) / 8 * 8 * (N / 384);
         std::vector<double> acc(32, 0.0); int c2 = 0;

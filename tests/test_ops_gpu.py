@@ -684,13 +684,15 @@ def test_linear_wide_tile_is_bit_identical(M, N, K, act, stream):
         pol.set_option("op_stream_T", 0)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("M,N,K,act,stream", [(16384, 768, 768, 0, 1), (16384, 768, 768, 0, 0), (16384, 2304, 128, 0, 0), (16384, 3072, 768, 3, 0),
                                               (24576, 1536, 3072, 1, 0), (32768, 768, 3072, 0, 1), (8192, 6144, 256, 0, 0)])
-def test_linear_q4_tile_is_bit_identical(M, N, K, act, stream):
+def test_linear_q4_tile_is_bit_identical(M, N, K, act, stream, mode):
     """gemm_q4_kernel (option gemm_q4: 256x384 tile on four waves, one per SIMD; Gray-code quadrant phases, rolling in-place fragment reloads,
     inline-asm MFMAs with 128 of the 384 accumulator registers in VGPRs) accumulates K in the same order with the same MFMA as every other tile
     shape: identical bits to the 256x256 ping-pong kernel (bias, activation, bf16 residual stream with its RMS partials), and the usual
-    agreement with torch. The shapes cover one to sixteen tiles per workgroup and 2 .. 48 K-tiles."""
+    agreement with torch. The shapes cover one to sixteen tiles per workgroup and 2 .. 48 K-tiles. mode 1: the 256x384 tile, mode 2: the 128x384 tile
+    (wave tile 64x192, its own LDS layout and wait counts)."""
     pol = bare_policy("bf16")
     pol.set_option("op_bf16_out", 1)
     pol.set_option("op_stream_T", stream)
@@ -702,7 +704,7 @@ def test_linear_q4_tile_is_bit_identical(M, N, K, act, stream):
         r = torch.randn(M, N, generator=g) * 3.0 if stream else None
         d = [None if t is None else t.cuda() for t in (A, W, b, None, r)]
         outs, kinds = [], []
-        for q4 in (0, 1):
+        for q4 in (0, mode):
             pol.set_option("gemm_q4", q4)
             out = torch.full((M, N), float("nan"), device="cuda")
             pol.prof_enable(True)
@@ -712,7 +714,7 @@ def test_linear_q4_tile_is_bit_identical(M, N, K, act, stream):
             kinds.append([l["kernel"] for l in pol.prof_read_gemm_launches()])
             pol.prof_enable(False)
             outs.append(out)
-        assert any("gemm_q4_kernel" in k for k in kinds[1]) and not any("gemm_q4_kernel" in k for k in kinds[0]), kinds
+        assert any("gemm_q4_kernel" in k and k.endswith(f", {3 - mode}>") for k in kinds[1]) and not any("gemm_q4_kernel" in k for k in kinds[0]), kinds
         assert torch.isfinite(outs[1]).all()
         assert torch.equal(outs[0], outs[1])
         ref = bf(A) @ bf(W).T + b

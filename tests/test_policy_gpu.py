@@ -1034,7 +1034,7 @@ def test_q4_gemm_tile_in_the_headline_batch_is_bit_identical():
     pol.prof_enable(False)
     pol.set_option("gemm_q4", 0)
     print(f"[q4] kernels in the headline step: {kinds}")
-    assert any(k.endswith("<0, 4>") for k in kinds) and any(k.endswith("<0, 5>") for k in kinds) and any(k.endswith("<0, 1>") for k in kinds) \
-        and any(k.endswith("<3, 1>") for k in kinds), kinds
+    assert any(k.endswith("<0, 4, 2>") for k in kinds) and any(k.endswith("<0, 5, 2>") for k in kinds) and any(k.endswith("<0, 1, 2>") for k in kinds) \
+        and any(k.endswith("<3, 1, 2>") for k in kinds), kinds
     for a, b, what in zip(ref, got, ("prompt tokens", "obs tokens", "logits")):
         assert torch.equal(a, b), what

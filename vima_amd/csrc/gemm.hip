@@ -749,11 +749,11 @@ __global__ __launch_bounds__(TL::THREADS, TL::MINW) void gemm_kernel(const GemmD
 // HAS_BIAS / HAS_RS (fused-RMSNorm row scale) are compile-time here: as runtime flags hipcc turned the conditional adds into
 // v_pk_add + one v_cndmask per value and kept the x rsc multiply -- 256 of the 321 VALU instructions per wave of a
 // bias-less, scale-less epilogue (every T5 GEMM) did nothing, and the epilogue is VALU-issue-bound (2 waves per SIMD).
-template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS, bool OUT8, int NI = 2>   // NI: 32-column blocks per wave (2: the 256x256 kernels' 128x64 block; 6: gemm_q4_kernel's 128x192)
-__device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f32x16_t (&acc)[4][NI], const float (&rscv)[4], char* slab,
+// NI / MI: 32-column / 32-row blocks per wave (2 / 4: the 256x256 kernels' 128x64 block; 6 / 4 and 6 / 2: gemm_q4_kernel's 128x192 and 64x192)
+template <int ACT, int EPI, bool W8, bool HAS_BIAS, bool HAS_RS, bool OUT8, int NI = 2, int MI = 4>
+__device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f32x16_t (&acc)[MI][NI], const float (&rscv)[MI], char* slab,
                                                        int lane, int m0, int n0, int wm, int wn) {
   using T = bf16_t;
-  constexpr int MI = 4;
   const int act = ACT >= 0 ? ACT : p.act;
   // ---------------------------------------------------------------- epilogue (32x32 fp32 slabs, private LDS region)
   // acc[mi][ni][4q+e] = C[m0 + wm*128 + mi*32 + l31][n0 + wn*64 + ni*32 + 8q + 4hi + e]
@@ -980,22 +980,22 @@ __device__ __forceinline__ void tile_epilogue_256_impl(const GemmDev& p, const f
   if (AUX) emit_stores(MI * NI - 1);
 }
 
-template <int ACT, int EPI, bool W8, bool OUT8 = true, int NI = 2>
-__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[4][NI], const float (&rscv)[4], char* slab,
+template <int ACT, int EPI, bool W8, bool OUT8 = true, int NI = 2, int MI = 4>
+__device__ __forceinline__ void tile_epilogue_256(const GemmDev& p, const f32x16_t (&acc)[MI][NI], const float (&rscv)[MI], char* slab,
                                                   int lane, int m0, int n0, int wm, int wn) {
   const bool hb = p.bias != nullptr;                                   // kernel arguments: wave-uniform branches
   const bool hr = (EPI == 0 || EPI == 1 || EPI == 5) && p.rs_ssq != nullptr;
   if constexpr (EPI == 0 || EPI == 1 || EPI == 5) {
     if (hb) {
-      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-      else tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, true, true, OUT8, NI, MI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8, NI, MI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     } else {
-      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-      else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      if (hr) tile_epilogue_256_impl<ACT, EPI, W8, false, true, OUT8, NI, MI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+      else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8, NI, MI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
     }
   } else {
-    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
-    else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8, NI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    if (hb) tile_epilogue_256_impl<ACT, EPI, W8, true, false, OUT8, NI, MI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
+    else tile_epilogue_256_impl<ACT, EPI, W8, false, false, OUT8, NI, MI>(p, acc, rscv, slab, lane, m0, n0, wm, wn);
   }
 }
 
@@ -2153,28 +2153,31 @@ int launch_wide(GemmDev d, const GemmArgs& a, hipStream_t st) {
   }
 }
 
-template <int ACT, int EPI>
+template <int ACT, int EPI, int MIH>
 int launch_q4_inst(const GemmDev& d, int grid, hipStream_t st) {
   static PerDeviceOnce attr;   // per instantiation, per device
   {
-    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<ACT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Q4::SMEM_BYTES); });
+    const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<ACT, EPI, MIH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Q4T<MIH>::SMEM_BYTES); });
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((gemm_q4_kernel<ACT, EPI>), dim3((unsigned)grid), dim3(Q4::THREADS), Q4::SMEM_BYTES, st, d);
+  hipLaunchKernelGGL((gemm_q4_kernel<ACT, EPI, MIH>), dim3((unsigned)grid), dim3(Q4::THREADS), Q4T<MIH>::SMEM_BYTES, st, d);
   return (int)hipGetLastError();
 }
 
-// 256 x 384 four-wave kernel (option gemm_q4): returns -1 when the problem does not fit it (caller falls back to the 256x256 kernels)
+// four-wave kernel (option gemm_q4: 1 = 256 x 384 tile, 2 = 128 x 384 tile): returns -1 when the problem does not fit it (caller falls back to the 256x256 kernels)
+template <int MIH>
 int launch_q4(GemmDev d, const GemmArgs& a, hipStream_t st) {
-  if (a.w8 || a.a8 || a.rb != 0 || a.batch > 1 || a.M % Q4::BM || a.N % Q4::BN || a.K < 128 || a.K % 128 || !d.wide8) return -1;
+  using QC = Q4T<MIH>;
+  if (a.w8 || a.a8 || a.rb != 0 || a.batch > 1 || a.M % QC::BM || a.N % QC::BN || a.K < 128 || a.K % 128 || !d.wide8) return -1;
   if ((long long)a.M * a.lda * 2 >= (1LL << 32) || (long long)a.N * a.ldw * 2 >= (1LL << 32)) return -1;
-  if (a.mul || a.res || a.out32 || a.out8 || a.split_n || a.pair32 || a.rs_ssq || a.sum_out) return -1;
+  if (a.mul || a.res || a.out32 || a.out8 || a.split_n || a.pair32 || a.sum_out || a.rs_sum) return -1;
+  if (a.rs_ssq && (MIH != 1 || a.rs_parts != 24 || a.resT)) return -1;   // fused-RMSNorm consumer: the 128 x 384 tile only (E = 768: 24 partials per row), bf16-output epilogues
   int epi = 0;
   if (!a.resT && !a.ssq_out) epi = a.hm_D ? 5 : 1;
   else if (a.resT && a.act == ACT_NONE && !a.hm_D) epi = 4;
   if (!epi) return -1;
-  if (epi == 5 && a.act != ACT_NONE) return -1;
+  if (epi == 5 && (a.act != ACT_NONE || a.hm_L % QC::BM != 0)) return -1;
   if (g_num_cu == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -2182,8 +2185,8 @@ int launch_q4(GemmDev d, const GemmArgs& a, hipStream_t st) {
     g_num_cu = n / 8 * 8;
     if (kLab) { const int lim = env_int("VIMA_GEMM_LAB_CUS", 0); if (lim >= 8 && lim < g_num_cu) g_num_cu = lim / 8 * 8; }
   }
-  d.mtiles = d.M / Q4::BM;
-  d.ntiles = d.N / Q4::BN;
+  d.mtiles = d.M / QC::BM;
+  d.ntiles = d.N / QC::BN;
   if ((long long)d.mtiles * d.ntiles < 128) return -1;
   d.vtotal = (d.mtiles + 7) / 8 * 8 * d.ntiles;
   d.raster = 0; d.epi_lds = 1; d.flat = 0;
@@ -2191,7 +2194,7 @@ int launch_q4(GemmDev d, const GemmArgs& a, hipStream_t st) {
   {   // n-groups whose W panels stay in an XCD's L2 (see launch_pp)
     static int kb = -1;
     if (kb < 0) kb = env_int("VIMA_GEMM_NGROUP_KB", 2560);
-    const long long panel = (long long)Q4::BN * a.K * 2;
+    const long long panel = (long long)QC::BN * a.K * 2;
     if (kb > 0 && a.K <= 1536 && (long long)d.ntiles * panel > (long long)kb * 1024) {
       int ng = (int)((long long)kb * 1024 / panel);
       if (ng < 1) ng = 1;
@@ -2201,12 +2204,12 @@ int launch_q4(GemmDev d, const GemmArgs& a, hipStream_t st) {
   }
   d.dbg = a.tune ? a.tune->gemm_dbg : nullptr;
   const int grid = d.vtotal < g_num_cu ? d.vtotal : g_num_cu;
-  if (epi == 5) return launch_q4_inst<ACT_NONE, 5>(d, grid, st);
+  if (epi == 5) return launch_q4_inst<ACT_NONE, 5, MIH>(d, grid, st);
   switch (a.act * 8 + epi) {
-    case ACT_NONE * 8 + 1: return launch_q4_inst<ACT_NONE, 1>(d, grid, st);
-    case ACT_RELU * 8 + 1: return launch_q4_inst<ACT_RELU, 1>(d, grid, st);
-    case ACT_QUICKGELU * 8 + 1: return launch_q4_inst<ACT_QUICKGELU, 1>(d, grid, st);
-    case ACT_NONE * 8 + 4: return launch_q4_inst<ACT_NONE, 4>(d, grid, st);
+    case ACT_NONE * 8 + 1: return launch_q4_inst<ACT_NONE, 1, MIH>(d, grid, st);
+    case ACT_RELU * 8 + 1: return launch_q4_inst<ACT_RELU, 1, MIH>(d, grid, st);
+    case ACT_QUICKGELU * 8 + 1: return launch_q4_inst<ACT_QUICKGELU, 1, MIH>(d, grid, st);
+    case ACT_NONE * 8 + 4: return launch_q4_inst<ACT_NONE, 4, MIH>(d, grid, st);
     default: return -1;
   }
 }
@@ -2524,8 +2527,25 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
     if (gemm_tile(a.tune) >= 7) large = false;
     if (a.split_n) large = false;   // after every override: the column-split output exists in the one-tile-per-workgroup / resident / skinny epilogues only
     if (large && gemm_q4(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {
-      const int e = launch_q4(d, a, st);
-      if (e >= 0) { if (a.kernel_id) *a.kernel_id = 19000 + (a.act + 1) * 10 + (a.hm_D ? 5 : (a.resT ? 4 : 1)); return e; }
+      // gemm_q4: 1 = the 256 x 384 tile wherever it fits, 2 = the 128 x 384 tile wherever it fits, 3 = the 128 x 384 tile where it needs fewer ROUNDS of the chip than
+      // the 256 x 256 tiling. A round of 128 x 384 tiles is 0.75 of a round of 256 x 256 tiles in FLOPs and measures ~0.8 of it in time (12 MFMAs per phase and barrier
+      // instead of 24); the margin keeps the choice away from ties. M = 16 384 (batch 32): N = 768 one round instead of one of 192 tiles, N = 1536 / 2304 2 / 3 rounds
+      // instead of 2 / 3 larger ones; the batch-256 shapes (M = 131 072, 81 920) never qualify. The choice depends on the SHAPE only, and the tile is bit-identical anyway.
+      int mode = gemm_q4(a.tune);
+      if (mode == 3) {
+        mode = 0;
+        if (a.M % 128 == 0 && a.N % 384 == 0 && a.M % 256 == 0 && a.N % 256 == 0) {
+          const long long ncu = 256;
+          const long long r_pp = ((long long)(a.M / 256) * (a.N / 256) + ncu - 1) / ncu;
+          const long long r_h = ((long long)(a.M / 128) * (a.N / 384) + ncu - 1) / ncu;
+          if (r_h * 80 <= r_pp * 93) mode = 2;
+        }
+      }
+      if (mode) {
+        const bool half = mode == 2;
+        const int e = half ? launch_q4<1>(d, a, st) : launch_q4<2>(d, a, st);
+        if (e >= 0) { if (a.kernel_id) *a.kernel_id = (half ? 20000 : 19000) + (a.act + 1) * 10 + (a.hm_D ? 5 : (a.resT ? 4 : 1)); return e; }
+      }
     }
     if (large && gemm_wide(a.tune) && gemm_tile(a.tune) == 0 && gemm_persist(a.tune) && gemm_raster(a.tune) == 0 && gemm_epi(a.tune)) {
       const int e = launch_wide(d, a, st);

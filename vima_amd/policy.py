@@ -536,7 +536,7 @@ class VIMAPolicy(nn.Module):
                    10: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 4>>", 11: "vima::gemm_resident_kernel<RTile<64, 32, 2, 1, 2>>",
                    12: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 2>>", 15: "vima::gemm_resident_kernel<RTile<32, 32, 1, 1, 2, true>> (GEGLU pair)",
                    16: "vima::gemm_resident_kernel<RTile<64, 64, 2, 2, 1, true>> (GEGLU pair)",
-                   17: "vima::gemm_skinny_kernel", 18: "vima::gemm_skinny_kernel (GEGLU pair)", 19: "vima::gemm_q4_kernel"}
+                   17: "vima::gemm_skinny_kernel", 18: "vima::gemm_skinny_kernel (GEGLU pair)", 19: "vima::gemm_q4_kernel", 20: "vima::gemm_q4_kernel"}
 
     def _gemm_kernel_name(self, kid: int) -> str:
         kind, rest = divmod(int(kid), 1000)
@@ -546,7 +546,9 @@ class VIMAPolicy(nn.Module):
             return f"{base}<{act - 1}, {epi}, true>"          # fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
         if kind == 1:
             return f"{base}<{act - 1}, {epi}, false>"
-        return f"{base}<{act - 1}, {epi}>" if kind in (2, 3, 19) else f"{base} act {act - 1}"
+        if kind in (19, 20):
+            return f"{base}<{act - 1}, {epi}, {2 if kind == 19 else 1}>"       # <ACT, EPI, MIH>: 256x384 / 128x384 tile
+        return f"{base}<{act - 1}, {epi}>" if kind in (2, 3) else f"{base} act {act - 1}"
 
     def prof_read_gemm_launches(self):
         """GEMM launches recorded since prof_enable(True), ONE BY ONE in launch order (call BEFORE prof_read / prof_read_ex) ->
