@@ -129,23 +129,27 @@ def test_q4_kernel_stream_is_what_was_written():
     src, _ = _compile("gemm.hip")
     res = _usage("gemm.hip")
     q4 = {k: v for k, v in res.items() if "gemm_q4_kernel" in k}
-    assert len(q4) >= 5, sorted(q4)
+    assert len(q4) >= 10, sorted(q4)                                   # five epilogue forms x two tiles (MIH = 2: 256x384, MIH = 1: 128x384)
+    mih_of = lambda name: int(re.search(r"gemm_q4_kernelILi\d+ELi\d+ELi(\d)E", name).group(1))
     for k, v in q4.items():
         assert v.get("ScratchSize", 0) == 0, (k, v)
-        assert v.get("AGPRs", 0) == 256 and v.get("VGPRs", 0) <= 256, (k, v)
+        # 16 (8) of the 24 (12) accumulator blocks live in AGPRs; the 128x384 tile's epilogue may park values in the free half of the AGPR file
+        assert (v.get("AGPRs", 0) == 256 if mih_of(k) == 2 else 128 <= v.get("AGPRs", 0) <= 256) and v.get("VGPRs", 0) <= 256, (k, v)
     checked = 0
     for m in re.finditer(r"^(_ZN4vima\S*gemm_q4_kernel\S*):", src, flags=re.M):
+        mih = mih_of(m.group(1))
         body = src[m.end():src.index(".Lfunc_end", m.end())].split("\n")      # (the kernel has an early exit: several s_endpgm)
         code = [ln.strip() for ln in body if ln.strip() and ln.strip()[0] not in ";."]
         idx = [i for i, ln in enumerate(code) if ln.startswith("v_mfma_f32_32x32x16_bf16")]
-        assert len(idx) == 192, (m.group(1), len(idx))                 # 8 phases x 24: ONE loop body
+        assert len(idx) == 96 * mih, (m.group(1), len(idx))            # 8 phases x 24 (12): ONE loop body
         loop = code[idx[0]:idx[-1] + 1]
         bad = [ln for ln in loop if re.match(r"(s_load|s_buffer_load|v_accvgpr|scratch_|s_cbranch|v_readlane|v_writelane)", ln)]
         assert not bad, (m.group(1), bad[:4])
-        assert sum(ln.startswith("ds_read_b128") for ln in loop) == 94, m.group(1)          # 2 K-tiles x 48 rolling reads (the last two follow the last MFMA)
-        assert sum(ln.startswith("global_load_lds_dwordx4") for ln in loop) == 40, m.group(1)   # 2 K-tiles x 20 pieces
+        # rolling reads per K-tile: P1 4 MIH, P2 12, P3 4 MIH, P4 4 (3 + MIH); the last two of the loop body follow its last MFMA
+        assert sum(ln.startswith("ds_read_b128") for ln in loop) == 2 * (24 + 12 * mih) - 2, m.group(1)
+        assert sum(ln.startswith("global_load_lds_dwordx4") for ln in loop) == 2 * (12 + 4 * mih), m.group(1)   # 2 K-tiles x (6 + 6 + 2 x 2 MIH) pieces
         assert sum(ln.startswith("s_barrier") for ln in loop) == 7, m.group(1)             # 8 phases (the last one's barrier follows the last MFMA)
         m0 = [ln for ln in code if re.search(r"\bm0\b", ln)]
         assert m0 and all(ln.startswith("s_mov_b32 m0, s") for ln in m0), (m.group(1), [ln for ln in m0 if not ln.startswith("s_mov_b32 m0, s")][:3])
         checked += 1
-    assert checked >= 5, checked
+    assert checked >= 10, checked
