@@ -14,6 +14,7 @@
 #   b1 | b32                 the same at batch 1 / 32 (cold steps)                      -> <tag>_b1_kernel_stats.md
 #   warm | inc               12 warm / incremental env steps (scripts/warm_steps.py)    -> <tag>_warm_kernel_stats.md
 #   warm1 | inc1             the same at batch 1 (the reference eval loop's steady state)
+#   gpt | gato | flamingo    kernel trace of a baseline policy's cold steps at batch 256     -> <tag>_<policy>_kernel_stats.md
 #   pmc                      FETCH_SIZE / WRITE_SIZE passes + per-shape join            -> <tag>_pmc_traffic.{md,json}
 #   sq                       SQ counter pass                                            -> <tag>_sq_counters.md
 #   py:<script args>         python <script args> (stdout -> <tag>_py_<n>.txt)
@@ -47,6 +48,8 @@ for task in "$@"; do
                 python $R/scripts/warm_steps.py $task 10 256 $arg;;
     warm1|inc1) prof $task "$TAG: ${task%1} steps at BATCH 1 (the reference eval loop's steady state: one obs ViT + decoder step + action head), VIMA-200M Lp=512 bf16 + one prompt assembly (python scripts/warm_steps.py ${task%1} 40 1 $arg)" \
                 python $R/scripts/warm_steps.py ${task%1} 40 1 $arg;;
+    gpt|gato|flamingo) prof $task "$TAG: $task BASELINE policy, batch 256, cold steps, dual_stream=0 (rocprofv3 --kernel-trace --stats -- python bench.py --policy $task --batch 256 --steps 4 --warmup 2 --opt dual_stream=0 $arg)" \
+                python $R/bench.py --policy $task --batch 256 --steps 4 --warmup 2 --opt dual_stream=0 $arg;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do
            rm -rf /tmp/pmc_$c
            (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only --live-pmc off --opt dual_stream=0 --launch-log /tmp/launches.json $arg > /dev/null 2>&1)

@@ -43,7 +43,9 @@ __device__ __forceinline__ void ld8(const float* p, float* f) {
 // vit_attn_lds_kernel, whose LDS image stores the four 16-byte chunks of a head permuted (bank conflicts); the VALUES and the order of
 // the arithmetic do not depend on it.
 struct ChunkId { __device__ __forceinline__ int operator[](int i) const { return i * 8; } };
-template <typename T, typename KR, typename VR, typename CO = ChunkId>
+// SM = the largest sequence the instantiation handles (8: object crops, 5 tokens; 16: the baseline policies' whole frames, cls + 8 patches = 9 tokens). Rows
+// j >= S contribute exp = 0.f to the sum and nothing else, so the result does not depend on SM.
+template <typename T, typename KR, typename VR, typename CO = ChunkId, int SM = 8>
 __device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, VR vrow, float (&o)[32], CO co = CO()) {
 #pragma clang fp contract(off)
   constexpr int D = 32;
@@ -51,10 +53,10 @@ __device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, 
 #pragma unroll
   for (int c = 0; c < D; c += 8) ld8(qp + co[c >> 3], q + c);
   const float scale = 0.17677669529663687f;  // 1/sqrt(32)
-  float s[8];
+  float s[SM];
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < SM; ++j) {
     s[j] = -INFINITY;
     if (j < S) {
       const T* kp = krow(j);
@@ -72,7 +74,7 @@ __device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, 
   }
   float l = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < SM; ++j) {
     s[j] = j < S ? expf(s[j] - mx) : 0.f;
     l += s[j];
   }
@@ -80,7 +82,7 @@ __device__ __forceinline__ void vit_head_attention(const T* qp, int S, KR krow, 
 #pragma unroll
   for (int c = 0; c < D; ++c) o[c] = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < SM; ++j) {
     if (j < S) {
       const T* vp = vrow(j);
       const float pj = s[j] * inv;
@@ -111,7 +113,7 @@ __device__ __forceinline__ void vit_store_head(const float (&o)[32], T* op, uint
   for (int c = 0; c < D; c += 4) store4(op + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
 }
 
-template <typename T>
+template <typename T, int SM = 8>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, long long total,
                                                         int S, int W, int heads, uint8_t* out8 = nullptr, float inv8 = 1.0f) {
   constexpr int D = 32;
@@ -122,8 +124,9 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qkv
   const long long m = mi / S;
   const int ld = 3 * W;
   float o[D];
-  vit_head_attention<T>(qkv + mi * ld + h * D, S, [&](int j) { return qkv + (m * S + j) * ld + W + h * D; },
-                        [&](int j) { return qkv + (m * S + j) * ld + 2 * W + h * D; }, o);
+  auto kr = [&](int j) { return qkv + (m * S + j) * ld + W + h * D; };
+  auto vr = [&](int j) { return qkv + (m * S + j) * ld + 2 * W + h * D; };
+  vit_head_attention<T, decltype(kr), decltype(vr), ChunkId, SM>(qkv + mi * ld + h * D, S, kr, vr, o);
   vit_store_head<T>(o, out + mi * W + h * D, out8 ? out8 + mi * W + h * D : nullptr, inv8);
 }
 
@@ -1053,7 +1056,7 @@ inline AttnDev to_dev(const AttnArgs& a) {
 
 int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, bool is_bf16, hipStream_t st, void* out8, float inv8) {
   if (M <= 0) return 0;
-  if (S > 8 || W / heads != 32 || W % heads || (out8 && !is_bf16)) return (int)hipErrorInvalidValue;
+  if (S > 16 || W / heads != 32 || W % heads || (out8 && !is_bf16)) return (int)hipErrorInvalidValue;
   static const bool lds_path = [] { const char* e = getenv("VIMA_VIT_ATTN_LDS"); return !(e && e[0] == '0'); }();
   if (is_bf16 && S == VA_S && W == VA_W && heads == VA_H && lds_path) {   // by shape only, never by the number of crops
     hipLaunchKernelGGL(vit_attn_lds_kernel, dim3((unsigned)((M + 1) / 2)), dim3(256), 2 * VA_S * VA_ROWB, st, (const bf16_t*)qkv, (bf16_t*)out, M,
@@ -1062,6 +1065,11 @@ int launch_vit_attn(const void* qkv, void* out, int M, int S, int W, int heads, 
   }
   const long long total = (long long)M * S * heads;
   const unsigned g = (unsigned)((total + 255) / 256);
+  if (S > 8) {   // 9 .. 16 tokens (the baseline policies' frames: cls + 8 patches): the same body with 16 score registers
+    if (is_bf16) hipLaunchKernelGGL((vit_attn_kernel<bf16_t, 16>), dim3(g), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, total, S, W, heads, (uint8_t*)out8, inv8);
+    else hipLaunchKernelGGL((vit_attn_kernel<float, 16>), dim3(g), dim3(256), 0, st, (const float*)qkv, (float*)out, total, S, W, heads);
+    return (int)hipGetLastError();
+  }
   if (is_bf16) hipLaunchKernelGGL(vit_attn_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, total, S, W, heads, (uint8_t*)out8, inv8);
   else hipLaunchKernelGGL(vit_attn_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)qkv, (float*)out, total, S, W, heads);
   return (int)hipGetLastError();
