@@ -34,6 +34,7 @@ def main():
     for _ in range(iters):
         _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 1, p(out), pol._stream()))
     torch.cuda.synchronize()
+    pr = pol.prof_read()["attention"]
     if os.environ.get("STAMPS"):   # needs a library built with -DVIMA_ATTN_STAMPS=1 (scripts/gpu_job_attn_ablate.sh pattern)
         nwg = B * H * ((Lq + 127) // 128) + 64
         dbg = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
@@ -53,7 +54,6 @@ def main():
         _lib.check(pol._lib.vima_op_attention(pol._handle, p(q), p(k), p(v), p(mask), p(rb), B, H, Lq, L, D, scale, mode, 0, p(ref), pol._stream()))
         torch.cuda.synchronize()
         print("  max |mfma - generic| =", (out - ref).abs().max().item(), "of", ref.abs().max().item())
-    pr = pol.prof_read()["attention"]
     ms = pr["ms"] / max(pr["launches"], 1)
     print(f"attn mode{mode} B{B} H{H} Lq{Lq} Lk{L} D{D}: {ms:.3f} ms = {4.0 * B * H * Lq * L * D / ms / 1e9:.1f} TFLOP/s")
 

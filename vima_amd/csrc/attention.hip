@@ -500,38 +500,16 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k);
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
 
-  // ---- workgroup-wide tables
+  // ---- workgroup-wide tables (filled further down, behind the first tile's LDS-DMA and the query loads)
   // madd[j]: additive key mask (0 / finfo.min; -inf beyond Lk so padded keys never contribute)
   // tflag[t]: 1 when tile t needs madd (a masked or out-of-range key), else the adds are skipped for the whole tile
-  // btab (T5): relative-position bias indexed by (key - query) + boff, zero-padded so that every index a lane of this
-  //            workgroup can form (including padded queries / keys) is in range -> no clamps in the inner loop
+  // btab (T5): relative-position bias indexed by (key - query) + boff for the queries of THIS workgroup, zero-padded so that every index a lane
+  //            can form (including padded queries / keys) is in range -> no clamps in the inner loop
   int* tflag = reinterpret_cast<int*>(madd + nt * 64);
   float* btab = reinterpret_cast<float*>(tflag + ((nt + 3) & ~3));
-  const int qpad = nq * QB, kpad = nt * 64;
-  const int boff = qpad - 1;                                   // index = key - qi + boff in [0, qpad + kpad - 2]
-  for (int j = tid; j < kpad; j += 256) {
-    float v = -INFINITY;
-    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lkr + j]) ? -FLT_MAX : 0.0f;
-    madd[j] = v;
-  }
-  if (MODE == ATTN_T5) {
-    const float* rb = p.relbias + (long long)h * (2 * p.Lk - 1);
-    for (int j = tid; j < qpad + kpad - 1; j += 256) {
-      const int delta = j - boff;                              // key - query
-      btab[j] = (delta > -p.Lk && delta < p.Lk) ? rb[delta + p.Lk - 1] * kLog2e : 0.0f;   // log2 domain, see below
-    }
-  }
-  __syncthreads();
-  if (tid < nt) {
-    int f = 0;
-    for (int j = 0; j < 64; ++j) f |= (madd[tid * 64 + j] != 0.0f) ? 1 : 0;
-    tflag[tid] = f;
-  }
-  // T5 with a table that is constant beyond +-bias_far (AttnArgs::bias_far): a key tile ALL of whose (key - query) lie beyond it for every query of
-  // this WAVE takes the constant as one scalar operand instead of 32 per-score LDS reads (16 ds_read2_b32 + their waits: 7 % of the tile's issue
-  // slots, profiles/r04_attention_ablation.txt: "nobias"); 43 % of the (wave, tile) pairs at L = 512, 69 % at L = 1024. Same values, same arithmetic.
+  const int kpad = nt * 64;
+  const int boff = qblk * QB + QB - 1;                         // index = key - qi + boff in [0, kpad + QB - 2]
   const int far = MODE == ATTN_T5 ? p.bias_far : 0;
-  const float cfar_pos = far > 0 ? btab[boff + far] : 0.0f, cfar_neg = far > 0 ? btab[boff - far] : 0.0f;
   const int qw0 = qblk * QB + w * (32 * QG), qw1 = qw0 + 32 * QG - 1;   // this wave's queries (wave-uniform)
 
   bf16x8_t qf[QG][KD];
@@ -565,13 +543,13 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   const bf16_t* Kb = K + b * p.k_bs + h * p.k_hs;
   const bf16_t* Vb = V + b * p.v_bs + h * p.v_hs;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem4;
-  auto k_key = [&](int i) { return ((w * NI + i) * 64 + lane) / CPR; };
-  auto k_chunk = [&](int i) { const int pp = ((w * NI + i) * 64 + lane) % CPR; return kswz<D>(k_key(i), pp); };
-  auto v_key = [&](int i) { return ((w * NI + i) & 1) * 32 + (lane >> 1); };
-  auto v_chunk = [&](int i) { return 2 * ((w * NI + i) >> 1) + (lane & 1); };
-  const unsigned kvo0 = (unsigned)(k_key(0) * p.ldk * 2 + k_chunk(0) * 16), vvo0 = (unsigned)(v_key(0) * p.ldv * 2 + v_chunk(0) * 16);
-  const unsigned kvo1 = NI > 1 ? (unsigned)(k_key(NI - 1) * p.ldk * 2 + k_chunk(NI - 1) * 16) : 0u;
-  const unsigned vvo1 = NI > 1 ? (unsigned)(v_key(NI - 1) * p.ldv * 2 + v_chunk(NI - 1) * 16) : 0u;
+  auto k_key = [&](int i, int ln) { return ((w * NI + i) * 64 + ln) / CPR; };
+  auto k_chunk = [&](int i, int ln) { const int pp = ((w * NI + i) * 64 + ln) % CPR; return kswz<D>(k_key(i, ln), pp); };
+  auto v_key = [&](int i, int ln) { return ((w * NI + i) & 1) * 32 + (ln >> 1); };
+  auto v_chunk = [&](int i, int ln) { return 2 * ((w * NI + i) >> 1) + (ln & 1); };
+  const unsigned kvo0 = (unsigned)(k_key(0, lane) * p.ldk * 2 + k_chunk(0, lane) * 16), vvo0 = (unsigned)(v_key(0, lane) * p.ldv * 2 + v_chunk(0, lane) * 16);
+  const unsigned kvo1 = NI > 1 ? (unsigned)(k_key(NI - 1, lane) * p.ldk * 2 + k_chunk(NI - 1, lane) * 16) : 0u;
+  const unsigned vvo1 = NI > 1 ? (unsigned)(v_key(NI - 1, lane) * p.ldv * 2 + v_chunk(NI - 1, lane) * 16) : 0u;
   auto dma_tile = [&](int t, int stg) {
     const char* kt = reinterpret_cast<const char*>(Kb + (long long)t * 64 * p.ldk);
     const char* vtp = reinterpret_cast<const char*>(Vb + (long long)t * 64 * p.ldv);
@@ -581,9 +559,11 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     if ((t + 1) * 64 > p.Lk) {   // workgroup-uniform: ragged last tile -> rows beyond Lk re-read the last key (masked by madd = -inf)
       const int last = p.Lk - 1 - t * 64;
       auto cl = [&](int key) { return key < last ? key : last; };
-      ko0 = (unsigned)(cl(k_key(0)) * p.ldk * 2 + k_chunk(0) * 16); vo0 = (unsigned)(cl(v_key(0)) * p.ldv * 2 + v_chunk(0) * 16);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // opaque: the geometry of this (at most one) tile is recomputed here instead of living in eight registers through the loop
+      ko0 = (unsigned)(cl(k_key(0, ln)) * p.ldk * 2 + k_chunk(0, ln) * 16); vo0 = (unsigned)(cl(v_key(0, ln)) * p.ldv * 2 + v_chunk(0, ln) * 16);
       if (NI > 1) {
-        ko1 = (unsigned)(cl(k_key(NI - 1)) * p.ldk * 2 + k_chunk(NI - 1) * 16); vo1 = (unsigned)(cl(v_key(NI - 1)) * p.ldv * 2 + v_chunk(NI - 1) * 16);
+        ko1 = (unsigned)(cl(k_key(NI - 1, ln)) * p.ldk * 2 + k_chunk(NI - 1, ln) * 16); vo1 = (unsigned)(cl(v_key(NI - 1, ln)) * p.ldv * 2 + v_chunk(NI - 1, ln) * 16);
       }
     }
     attn_glds16(kt, ko0, kl);
@@ -602,9 +582,71 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  dma_tile(0, 0);   // (the ring is disjoint from the tables; tflag becomes visible with the barrier below)
+  dma_tile(0, 0);   // (the ring is disjoint from the tables)
   if (NSTG > 2 && nt > 1) dma_tile(1, 1);
-  wait_tile_and_barrier(NSTG > 2 && nt > 1 ? 1 : 0);
+  // ---- the tables, while the first tile and the query fragments are in flight. Every thread's global reads of a table are issued before the first
+  // is used (one memory latency per table instead of one per 256 entries: the prologue is a third of this kernel's time at 8 key tiles per workgroup)
+  {
+    // key j = u * 256 + tid: wave w of pass u holds exactly tile 4 u + w, so the tile flag is a ballot
+    const int npass = (kpad + 255) >> 8;
+    const unsigned char* km = p.kmask ? reinterpret_cast<const unsigned char*>(p.kmask) + (long long)b * p.Lkr : nullptr;
+    for (int u0 = 0; u0 < npass; u0 += 4) {
+      unsigned char mk[4];
+      // (unconditional loads at clamped addresses, consumed by an empty asm: otherwise hipcc sinks each load into the branch that uses it and waits there)
+      unsigned mw[4] = {1u, 1u, 1u, 1u};
+      if (km) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = (u0 + u) * 256 + tid;
+          mw[u] = km[j < p.Lk ? j : p.Lk - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(mw[u]));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mk[u] = (unsigned char)mw[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = (u0 + u) * 256 + tid;
+        const float v = j < p.Lk ? (mk[u] ? 0.0f : -FLT_MAX) : -INFINITY;
+        if (j < kpad) madd[j] = v;
+        const bool nz = j < kpad && v != 0.0f;
+        const bool anyz = __any(nz);
+        const int tile = (u0 + u) * 4 + w;
+        if (lane == 0 && tile < nt) tflag[tile] = anyz ? 1 : 0;
+      }
+    }
+  }
+  if (MODE == ATTN_T5) {
+    const float* rb = p.relbias + (long long)h * (2 * p.Lk - 1);
+    const int nb = kpad + QB - 1;
+    for (int j0 = tid; j0 < nb; j0 += 1024) {
+      float bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int delta = j0 + u * 256 - boff;                 // key - query
+        const int ix = delta + p.Lk - 1;
+        bv[u] = rb[ix < 0 ? 0 : (ix > 2 * p.Lk - 2 ? 2 * p.Lk - 2 : ix)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bv[u]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int delta = j0 + u * 256 - boff;
+        if (!(delta > -p.Lk && delta < p.Lk)) bv[u] = 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u * 256 < nb) btab[j0 + u * 256] = bv[u] * kLog2e;   // log2 domain, see below
+    }
+  }
+  wait_tile_and_barrier(NSTG > 2 && nt > 1 ? 1 : 0);   // tile 0 has landed, the tables are visible
+  // T5 with a table that is constant beyond +-bias_far (AttnArgs::bias_far): a key tile ALL of whose (key - query) lie beyond it for every query of
+  // this WAVE takes the constant as one scalar operand instead of 32 per-score LDS reads (16 ds_read2_b32 + their waits: 7 % of the tile's issue
+  // slots, profiles/r04_attention_ablation.txt: "nobias"); 43 % of the (wave, tile) pairs at L = 512, 69 % at L = 1024. Same values, same arithmetic.
+  // (An index outside this workgroup's table belongs to a distance none of its tiles has.)
+  const float cfar_pos = (far > 0 && boff + far < kpad + QB - 1) ? btab[boff + far] : 0.0f;
+  const float cfar_neg = (far > 0 && boff - far >= 0) ? btab[boff - far] : 0.0f;
   // The query fragments were requested above with plain global loads. hipcc's wait-count pass carries "these loads may
   // still be pending" into the key-tile loop (it cannot know they landed during the first iteration) and therefore put
   // `s_waitcnt vmcnt(3..0)` in front of the first S^T MFMAs of EVERY iteration -- right behind the prefetch loads of the next
@@ -1122,7 +1164,7 @@ static int launch_mfma4_qg(const AttnDev& d, const AttnArgs& a, hipStream_t st) 
   const int nq = (a.Lq + 128 * QG - 1) / (128 * QG);
   constexpr int NSTG = QG > 1 ? VIMA_ATTN_NSTG2 : VIMA_ATTN_NSTG1;   // as in the kernel
   const size_t sh = NSTG * (64 * D * 2) + NSTG * (D * VT4_STRIDE * 2) + (size_t)nt * 64 * 4 + (size_t)((nt + 3) & ~3) * 4 +
-                    (MODE == ATTN_T5 ? (size_t)(nq * 128 * QG + nt * 64) * 4 : 0);
+                    (MODE == ATTN_T5 ? (size_t)(128 * QG + nt * 64) * 4 : 0);
   if (sh > 160 * 1024) return (int)hipErrorInvalidValue;
   static PerDeviceOnce attr;   // per instantiation, per device
   {
