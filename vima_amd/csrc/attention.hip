@@ -871,10 +871,18 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_split_kernel(const 
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k);
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v);
 
-  for (int j = tid; j < nt * SPLIT_TK; j += 256) {
-    float v = -INFINITY;
-    if (j < p.Lk) v = (p.kmask && !p.kmask[(long long)b * p.Lkr + j]) ? -FLT_MAX : 0.0f;
-    madd[j] = v;
+  // The additive key mask table. Its reads are ISSUED here, ahead of the query and K / V loads, and consumed behind them (unconditional clamped loads + an empty asm:
+  // as a loop of conditional loads hipcc waited for each one where it was issued, i.e. a workgroup that lives for four K / V round trips spent two more on its mask
+  // before it requested its first tile)
+  const uint8_t* km = p.kmask ? p.kmask + (long long)b * p.Lkr : nullptr;
+  const int nk = nt * SPLIT_TK;
+  unsigned mw0[4] = {1u, 1u, 1u, 1u};
+  if (km) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = tid + u * 256;
+      mw0[u] = km[j < p.Lk ? j : p.Lk - 1];
+    }
   }
   const int qrow = qi < p.Lq ? qi : p.Lq - 1;
   bf16x8_t qf[KD];
@@ -953,6 +961,29 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_split_kernel(const 
   using Set1 = std::integral_constant<int, 1>;
   gload(0, Set0{});
   if (nt > 1) gload(1, Set1{});
+  if (km) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(mw0[u]));
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = tid + u * 256;
+    if (j < nk) madd[j] = j < p.Lk ? ((mw0[u] & 0xffu) ? 0.0f : -FLT_MAX) : -INFINITY;
+  }
+  for (int j0 = tid + 1024; j0 < nk; j0 += 1024) {             // prompts beyond 1024 keys
+    unsigned mw[4] = {1u, 1u, 1u, 1u};
+    if (km) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mw[u] = km[j0 + u * 256 < p.Lk ? j0 + u * 256 : p.Lk - 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(mw[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 256;
+      if (j < nk) madd[j] = j < p.Lk ? ((mw[u] & 0xffu) ? 0.0f : -FLT_MAX) : -INFINITY;
+    }
+  }
   lstore(0, Set0{});
   __syncthreads();
   // wait for the query fragments ONCE, here: otherwise the wait-count pass waits for them in front of the first MFMAs of every
