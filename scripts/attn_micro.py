@@ -23,6 +23,11 @@ def main():
     k = torch.randn(B, L, H, D, device="cuda") * 0.4
     v = torch.randn(B, L, H, D, device="cuda")
     mask = torch.ones(B, L, dtype=torch.bool, device="cuda")
+    if os.environ.get("MASKF"):   # fraction of masked keys, scattered (the benchmark's prompts: 0.1); key 0 stays valid, batch row 1 is fully masked
+        mask = torch.rand(B, L, device="cuda") >= float(os.environ["MASKF"])
+        mask[:, 0] = True
+        if B > 1:
+            mask[1] = False
     rb = torch.randn(H, 2 * L - 1, device="cuda")
     out = torch.empty(B, Lq, H, D, device="cuda")
     p = lambda t: ctypes.c_void_p(t.data_ptr())

@@ -509,6 +509,11 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
   float* btab = reinterpret_cast<float*>(tflag + ((nt + 3) & ~3));
   const int kpad = nt * 64;
   const int boff = qblk * QB + QB - 1;                         // index = key - qi + boff in [0, kpad + QB - 2]
+  // T5 / cross mode: the mask enters as the S^T accumulators' initial value (see the key loop); its "minus infinity" for a masked key is then multiplied by
+  // log2(e) (or the score scale) with the rest of the score, so it is -1e38 instead of finfo.min: it absorbs any score all the same (masked keys weigh exactly 0,
+  // a row without a single valid key still comes out uniform) and stays finite
+  constexpr bool CINIT = MODE != ATTN_CAUSAL;
+  constexpr float kMaskNeg = -1.0e38f;
   const int far = MODE == ATTN_T5 ? p.bias_far : 0;
   const int qw0 = qblk * QB + w * (32 * QG), qw1 = qw0 + 32 * QG - 1;   // this wave's queries (wave-uniform)
 
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = (u0 + u) * 256 + tid;
-        const float v = j < p.Lk ? (mk[u] ? 0.0f : -FLT_MAX) : -INFINITY;
+        const float v = j < p.Lk ? (mk[u] ? 0.0f : (CINIT ? kMaskNeg : -FLT_MAX)) : -INFINITY;
         if (j < kpad) madd[j] = v;
         const bool nz = j < kpad && v != 0.0f;
         const bool anyz = __any(nz);
@@ -681,22 +686,39 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     const int k0 = t * 64;
     // ---- S^T for the two 32-key sub-tiles (alternating the two accumulators per k-step measured 7 % slower); every K
     // fragment is read once and multiplied with the queries of all QG groups
+    // T5 / cross mode: a tile with masked keys starts its accumulators from the additive key mask (0 / kMaskNeg / -inf per key row) instead of adding it to
+    // the 32 scores afterwards: the huge negative absorbs the dot product exactly as it absorbed the finished score (the benchmark masks 10 % of the prompt
+    // objects, i.e. nearly every tile takes this path). The causal mode keeps the explicit add: there the -1e4 fill REPLACES the score before the mask goes on.
     f32x16_t s[QG][2];
+    const bool masked_tile = tflag[t] != 0;                    // workgroup-uniform
+    auto st_mfmas = [&](auto init_c) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int g = 0; g < QG; ++g)
+        for (int g = 0; g < QG; ++g) {
+          if constexpr (decltype(init_c)::value) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[g][sub][r] = 0.f;
-      const int row = sub * 32 + l31;
+            for (int gg = 0; gg < 4; ++gg) {
+              const float4 ma = *reinterpret_cast<const float4*>(madd + k0 + sub * 32 + 8 * gg + 4 * hi);
+              s[g][sub][4 * gg + 0] = ma.x; s[g][sub][4 * gg + 1] = ma.y; s[g][sub][4 * gg + 2] = ma.z; s[g][sub][4 * gg + 3] = ma.w;
+            }
+          } else {
 #pragma unroll
-      for (int dd = 0; dd < KD; ++dd) {
-        const uint4 u = *reinterpret_cast<const uint4*>(ks + row * ROWB + (kswz<D>(row, dd * 2 + hi) << 4));
+            for (int r = 0; r < 16; ++r) s[g][sub][r] = 0.f;
+          }
+        }
+        const int row = sub * 32 + l31;
 #pragma unroll
-        for (int g = 0; g < QG; ++g)
-          s[g][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[g][dd], s[g][sub], 0, 0, 0);
+        for (int dd = 0; dd < KD; ++dd) {
+          const uint4 u = *reinterpret_cast<const uint4*>(ks + row * ROWB + (kswz<D>(row, dd * 2 + hi) << 4));
+#pragma unroll
+          for (int g = 0; g < QG; ++g)
+            s[g][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, u), qf[g][dd], s[g][sub], 0, 0, 0);
+        }
       }
-    }
+    };
+    if (CINIT && masked_tile) st_mfmas(std::true_type{});
+    else st_mfmas(std::false_type{});
     mark(1);   // S^T MFMAs issued
     // ---- scores -> probabilities (fp32), in the LOG2 domain: x' = log2(e) * (scaled score + bias) is ONE fma per element
     // (the bias table is pre-multiplied), p = exp2(x' - m'). The additive key mask (0 / -finfo.max / -inf) is added
@@ -705,7 +727,6 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
     // invariant to the reference point; p <= 256 keeps bf16 relative precision and fp32 sums exact enough), which
     // removes the O^T rescale from almost every tile.
     uint32_t pk[QG][2][8];
-    const bool masked_tile = tflag[t] != 0;                    // workgroup-uniform
     const float csc = (MODE == ATTN_T5 ? 1.0f : p.scale) * kLog2e;
     // wave-uniform: every (key - query) of this tile and wave at or beyond +far / -far
     const bool far_pos = MODE == ATTN_T5 && far > 0 && k0 - qw1 >= far, far_neg = MODE == ATTN_T5 && far > 0 && k0 + 63 - qw0 <= -far;
@@ -738,7 +759,7 @@ __global__ __launch_bounds__(256, QG > 1 ? 2 : (D == 32 ? 4 : 3)) void attn_mfma
         }
       }
       }
-      if (masked_tile) {
+      if (masked_tile && !CINIT) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
