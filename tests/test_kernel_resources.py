@@ -153,3 +153,26 @@ def test_q4_kernel_stream_is_what_was_written():
         assert m0 and all(ln.startswith("s_mov_b32 m0, s") for ln in m0), (m.group(1), [ln for ln in m0 if not ln.startswith("s_mov_b32 m0, s")][:3])
         checked += 1
     assert checked >= 10, checked
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_attention_prologue_issues_its_table_loads_in_batches():
+    """attn_mfma4_kernel's mask and bias tables: hipcc once sank every table load into the branch that used it and waited for it there
+    (6-8 serial memory latencies per workgroup, the first of them also waiting for the first key tile's LDS-DMA: -5 % on the T5 shape,
+    profiles/r06_attention_experiments.txt). The source now issues four unconditional clamped loads per table pass and consumes them
+    with an empty asm; this audits the generated ISA of the T5 instantiation: in front of the first barrier, every group of table
+    loads is complete before the first wait that follows its first load, and the first tile's LDS-DMA is requested before any of them."""
+    src, _ = _compile("attention.hip")
+    m = re.search(r"^(_ZN4vima\S*attn_mfma4_kernelILi64ELi0ELi1EEE\S*):", src, flags=re.M)
+    assert m, "attn_mfma4_kernel<64, T5, 1> not found"
+    body = src[m.end():src.index("s_barrier", m.end())].split("\n")
+    ops = [re.split(r"[\s,]+", l.strip())[0] + (" " + l.strip() if "s_waitcnt" in l else "") for l in body if l.strip() and l.strip()[0] not in ";."]
+    first_dma = next(i for i, o in enumerate(ops) if o.startswith("global_load_lds_dwordx4"))
+    for kind in ("global_load_ubyte", "global_load_dword"):
+        idx = [i for i, o in enumerate(ops) if o.split(" ")[0] == kind]
+        assert len(idx) >= 4, (kind, len(idx))
+        assert first_dma < idx[0], "the first key tile is requested before the tables are read"
+        # groups of four consecutive loads (no wait on the vector-memory counter between the first and the last of a group)
+        for g in range(0, len(idx) - len(idx) % 4, 4):
+            between = ops[idx[g]:idx[g + 3]]
+            assert not any("vmcnt" in o for o in between), (kind, g, between)
