@@ -13,7 +13,10 @@ branch of `cv::resize` with "area" source coordinates when the crop is SMALLER t
 behaviour; it could not be checked against cv2 outputs here. What IS pinned: the integer paths (bbox, crop, padding,
 slot order, masks) against a literal numpy re-run of the reference's own loop (`reference_loop_obs`, which is the
 reference's code path with only the cv2 call swapped for `resize_area_32`), and the resize against known-answer
-properties (identity at 32 px, exact block means at integer factors, constants stay constant).
+properties (identity at 32 px, exact block means at integer factors, constants stay constant) and two independent
+computations (tests/test_preprocess_crosscheck.py): the geometric definition of area resampling in float64 for the
+fractional regime (agreement to half a grey level, i.e. the rounded exact mean) and Pillow's BOX filter for integer
+factors (one grey level: Pillow rounds between its passes). That pins the geometry, not OpenCV's rounding.
 
 Everything is integer / uint8 work and is compared BIT-EXACTLY with the HIP kernels (tests/test_preprocess_gpu.py).
 """
