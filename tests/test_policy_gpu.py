@@ -1038,3 +1038,30 @@ def test_q4_gemm_tile_in_the_headline_batch_is_bit_identical():
         and any(k.endswith("<3, 1, 2>") for k in kinds), kinds
     for a, b, what in zip(ref, got, ("prompt tokens", "obs tokens", "logits")):
         assert torch.equal(a, b), what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,qv,chunk", [(291, 4, 0), (700, 4, 2600)])
+def test_vit_padded_chunks_are_bit_identical(n, qv, chunk):
+    """Option vit_pad (default on): a ViT pass over a crop count that is not a multiple of 256 is computed on the next multiple (zero-image pad crops whose features
+    nobody reads), so that its GEMMs keep the 256-row tile kernels; ObjEncoder.forward (obj_encoder.py:66-95) must return the same bits as the unpadded pass
+    (every kernel on the way is row-wise, and the tile kernels are bit-identical to one another). 2 n qv = 2 328 crops in one pass, and 5 600 crops in chunks
+    of 2 816 (the last one padded) on two streams."""
+    cfg = syn.config("4M")
+    sd = syn.make_state_dict(cfg, 5)
+    pol = loaded_policy(cfg, sd, "bf16")
+    g = torch.Generator().manual_seed(n)
+    objs = syn._objects(g, (n,), qv)
+    crops, bbox = syn.to_device(objs["cropped_img"], DEV), syn.to_device(objs["bbox"], DEV)
+    if chunk:
+        pol.set_option("vit_chunk", chunk)
+    try:
+        pol.set_option("vit_pad", 1)
+        a = pol.obj_encoder(crops, bbox).clone()
+        pol.set_option("vit_pad", 0)
+        b = pol.obj_encoder(crops, bbox).clone()
+    finally:
+        pol.set_option("vit_pad", 1)
+        pol.set_option("vit_chunk", 16384)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), max_abs(a, b)
