@@ -1065,3 +1065,30 @@ def test_vit_padded_chunks_are_bit_identical(n, qv, chunk):
         pol.set_option("vit_chunk", 16384)
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), max_abs(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(10, 496), (5, 500)])
+def test_t5_padded_rows_are_bit_identical(B, L):
+    """Option t5_pad (default on): a T5 pass whose row count per stream (2 480 = 5 x 496, or 2 500 on one stream) is not a multiple of 256 is computed on the next
+    multiple -- zero pad rows through the GEMM chain, no attention launch sees them -- so that T5PromptEncoder's GEMMs (prompt_encoder.py:681-825) keep the 256-row
+    tile kernels; the encoder output must be the same bits as the unpadded pass."""
+    cfg = syn.config("4M")
+    sd = syn.make_state_dict(cfg, 7)
+    pol = loaded_policy(cfg, sd, "bf16")
+    g = torch.Generator().manual_seed(B * L)
+    x = torch.randn(B, L, 768, generator=g).to(DEV)
+    mask = torch.rand(B, L, generator=g) > 0.1
+    mask[:, 0] = True
+    try:
+        if B < 8:
+            pol.set_option("dual_stream", 0)
+        pol.set_option("t5_pad", 1)
+        a = pol.t5_encode(x, mask.to(DEV)).clone()
+        pol.set_option("t5_pad", 0)
+        b = pol.t5_encode(x, mask.to(DEV)).clone()
+    finally:
+        pol.set_option("t5_pad", 1)
+        pol.set_option("dual_stream", 1)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), max_abs(a, b)

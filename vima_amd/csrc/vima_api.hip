@@ -196,6 +196,7 @@ struct VimaHandle {
   int attn_impl = 1;
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
   int vit_chunk = 16384;
+  int t5_pad = 1;                                 // option "t5_pad": the T5 stack's GEMMs run on the next multiple of 256 rows (pad rows: zeros in, never read) when B * L is not one
   int vit_pad = 1;                                // option "vit_pad": ViT chunks of >= 2048 crops run on a multiple of 256 crops (pad crops computed and never read), so that their
                                                  // GEMMs keep the 256x256 kernels at ANY crop count (a chunk of 13 654 crops: 57.8 -> 53.5 ms on the headline workload)
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
@@ -1238,8 +1239,9 @@ const float* t5_layer_fp8(Run& R, const VimaHandle::T5Layer& Ly, const uint8_t* 
 }
 
 const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, const uint8_t* mask, const float* table, int B,
-                            int L, const T5Buf& b, int attn_impl, const float* ssq_in, int parts_in, float* amax = nullptr) {
+                            int L, const T5Buf& b, int attn_impl, const float* ssq_in, int parts_in, float* amax = nullptr, int rows_gemm = 0) {
   const int rows = B * L;
+  const int mrows = rows_gemm > rows ? rows_gemm : rows;      // option t5_pad: the GEMMs' row count (>= rows, a multiple of 256; the buffers hold that many)
   constexpr int kParts = kT5Model / 32;
   // calibration of the fp8 activation scales: max |x| of the four GEMM inputs of this layer (bf16 tensors)
   auto cal = [&](int site, const void* t, int cols) {
@@ -1249,7 +1251,7 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
   auto gemm = [&](const void* A, int lda, const Lin& W, int act, const float* res, float* out32, void* outT, int ldT,
                   const float* rs, int rs_parts, float* ssq_out) {
     GemmArgs g;
-    g.A = A; g.lda = lda; R.setW(g, W); g.M = rows; g.N = W.N; g.K = W.K; g.act = act;
+    g.A = A; g.lda = lda; R.setW(g, W); g.M = mrows; g.N = W.N; g.K = W.K; g.act = act;
     g.res = res; g.ldres = kT5Model; g.out32 = out32; g.ld32 = kT5Model; g.outT = outT; g.ldT = ldT;
     g.rs_ssq = rs; g.rs_parts = rs_parts; g.rs_invk = 1.0f / (float)kT5Model; g.rs_eps = 1e-6f;
     g.ssq_out = ssq_out;
@@ -1271,7 +1273,7 @@ const float* t5_layer_fused(Run& R, const VimaHandle::T5Layer& Ly, float* x, con
     // traffic per stream element and residual GEMM).
     auto gemm_s = [&](const void* A, int lda, const Lin& W, float* ssq_out) {
       GemmArgs g;
-      g.A = A; g.lda = lda; R.setW(g, W); g.M = rows; g.N = W.N; g.K = W.K; g.act = ACT_NONE;
+      g.A = A; g.lda = lda; R.setW(g, W); g.M = mrows; g.N = W.N; g.K = W.K; g.act = ACT_NONE;
       g.resT = b.hT; g.ldresT = kT5Model; g.outT = b.hT; g.ldT = kT5Model; g.ssq_out = ssq_out;
       return R.gemm(g);
     };
@@ -1303,8 +1305,16 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   const bool dual = h->dual_stream && B >= 2;
   const int nb[2] = {dual ? B - B / 2 : B, dual ? B / 2 : 0};
   T5Buf buf[2];
+  // option t5_pad: a half whose row count is not a multiple of 256 (the 256x256 tile kernels take nothing else) is computed on the next multiple when it has at
+  // least 2048 rows: the pad rows enter as zeros, run through the GEMM chain like any row, are neither attended to nor read back (fused RMSNorm chain with the
+  // stream in the operand type only; the fp8-activation layers need whole tiles of REAL rows and are left alone)
+  int rpad[2] = {0, 0};
   for (int i = 0; i < (dual ? 2 : 1); ++i) {
-    const size_t rows = (size_t)nb[i] * L;
+    const long long r = (long long)nb[i] * L;
+    if (h->t5_pad && h->t5_fuse_rms && h->stream_T && r >= 2048 && r % 256 != 0 && !gemm_splitk_enabled(&h->tune)) rpad[i] = (int)((r + 255) / 256 * 256);
+  }
+  for (int i = 0; i < (dual ? 2 : 1); ++i) {
+    const size_t rows = rpad[i] ? (size_t)rpad[i] : (size_t)nb[i] * L;
     buf[i].hT = R.wsT(rows * kT5Model);
     buf[i].qkv = R.wsT(rows * 3 * kT5Model);
     buf[i].ctx = R.wsT(rows * kT5Model);
@@ -1376,6 +1386,14 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
     OTHER(R, launch_quant_fp8(buf[0].hT, kT5Model, (long long)nb[0] * L, kT5Model, 1.0f / h->fp8_scale[0], buf[0].h8, kT5Model, R.st), "quant_fp8");
     if (dual) OTHER(Rb, launch_quant_fp8(buf[1].hT, kT5Model, (long long)nb[1] * L, kT5Model, 1.0f / h->fp8_scale[0], buf[1].h8, kT5Model, Rb.st), "quant_fp8");
   }
+  for (int i = 0; i < (dual ? 2 : 1); ++i)
+    if (rpad[i]) {   // zero pad rows: stream entry, its row statistics, and the attention output rows no attention launch writes
+      Run& Ri = i ? Rb : R;
+      const long long r = (long long)nb[i] * L, np = rpad[i] - r;
+      HIPCK(hipMemsetAsync(Ri.offT(buf[i].hT, r * kT5Model), 0, (size_t)np * kT5Model * h->esz(), Ri.st));
+      HIPCK(hipMemsetAsync(Ri.offT(buf[i].ctx, r * kT5Model), 0, (size_t)np * kT5Model * h->esz(), Ri.st));
+      HIPCK(hipMemsetAsync(buf[i].ssB + r * (kT5Model / 32), 0, (size_t)np * (kT5Model / 32) * sizeof(float), Ri.st));
+    }
   for (int l = 0; l < kT5Layers; ++l) {
     if (run8) {
       float sc[5];
@@ -1386,8 +1404,8 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
       parts = kT5Model / 32;
     } else if (fused) {
       float* am = calibrate ? h->fp8_amax + l * 4 : nullptr;
-      ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts, am);
-      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x1, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts, am);
+      ss[0] = t5_layer_fused(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl, ss[0], parts, am, rpad[0]);
+      if (dual) ss[1] = t5_layer_fused(Rb, h->t5[l], x1, mask + off1, table, nb[1], L, buf[1], h->attn_impl, ss[1], parts, am, rpad[1]);
       parts = kT5Model / 32;
     } else {
       t5_layer(R, h->t5[l], x, mask, table, nb[0], L, buf[0], h->attn_impl);
@@ -1678,6 +1696,7 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "attn_split") h->tune.attn_split = (int)value;
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_pad") h->vit_pad = (int)value;
+  else if (k == "t5_pad") h->t5_pad = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else if (k == "dual_stream") h->dual_stream = (int)value;
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
