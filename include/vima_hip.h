@@ -295,7 +295,7 @@ int vima_t5_bucket(int relative_position);
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass
  *                            "t5_pad"       [1] the T5 stack is computed on the next multiple of 256 rows when batch x prompt length (>= 2048 rows per stream) is not one (zero pad rows, never read)
- *                            "vit_pad"      [1] ViT passes of >= 2048 crops are computed on a multiple of 256 crops (zero-image pad crops, never read) so their GEMMs stay on the 256-row tile kernels at any crop count
+ *                            "vit_pad"      [1] ViT passes of >= 1024 crops are computed on a multiple of 256 crops (zero-image pad crops, never read) so their GEMMs stay on the 256-row tile kernels at any crop count
  *   test / instrumentation:  "op_bf16_out", "op_stream_T" (route vima_op_linear through the bf16-output / bf16-residual
  *                            epilogues; op_stream_T also feeds vima_op_layernorm a bf16 input), "op_bias_far" (vima_op_attention, T5 mode: promise
  *                            that the relbias table is constant from that |key - query| on, as the bucketed T5 table is from 91; 0 = no promise),

@@ -197,7 +197,7 @@ struct VimaHandle {
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
   int vit_chunk = 16384;
   int t5_pad = 1;                                 // option "t5_pad": the T5 stack's GEMMs run on the next multiple of 256 rows (pad rows: zeros in, never read) when B * L is not one
-  int vit_pad = 1;                                // option "vit_pad": ViT chunks of >= 2048 crops run on a multiple of 256 crops (pad crops computed and never read), so that their
+  int vit_pad = 1;                                // option "vit_pad": ViT chunks of >= 1024 crops run on a multiple of 256 crops (pad crops computed and never read), so that their
                                                  // GEMMs keep the 256x256 kernels at ANY crop count (a chunk of 13 654 crops: 57.8 -> 53.5 ms on the headline workload)
   int vit_prune_last = 1;   // compute the last ViT block only for the cls token (only row ln_post reads)
   int stream_T = 1;         // residual stream of the T5 stack carried in the operand type (bf16) instead of fp32 + bf16 copy:
@@ -1048,7 +1048,7 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
   int chunk = (M + nchunks - 1) / nchunks;
   // option vit_pad: chunks of a multiple of 256 crops (5 rows per crop: only then are the ViT's GEMMs whole 256-row tiles); the last chunk is computed on the
   // next multiple of 256 when that costs at most an eighth more rows (its pad crops are zero images whose features land behind row M of cat)
-  const bool pad = h->vit_pad != 0 && chunk >= 2048;
+  const bool pad = h->vit_pad != 0 && chunk >= 1024;   // (5 120 rows: from there on the wide-N GEMMs of a chunk fill the chip with 256x256 tiles)
   if (pad) chunk = (chunk + 255) / 256 * 256;
   void* cat = R.wsT((size_t)(M + (pad ? 256 : 0)) * 2 * kVitW);   // [M (+ pad), 1536] = [vit feature | bbox feature]
   VitBuf vb[2];
