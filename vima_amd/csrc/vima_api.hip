@@ -196,6 +196,8 @@ struct VimaHandle {
   int attn_impl = 1;
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
   int vit_chunk = 16384;
+  int dual_t5_rows = 0;                           // option "dual_t5_rows": batch x prompt length from which the T5 stack splits the batch over two streams (with dual_stream)
+  int dual_vit_crops = 512;                       // option "dual_vit_crops": crop count from which the ViT alternates its chunks between two streams (with dual_stream)
   int t5_pad = 1;                                 // option "t5_pad": the T5 stack's GEMMs run on the next multiple of 256 rows (pad rows: zeros in, never read) when B * L is not one
   int vit_pad = 1;                                // option "vit_pad": ViT chunks of >= 1024 crops run on a multiple of 256 crops (pad crops computed and never read), so that their
                                                  // GEMMs keep the 256x256 kernels at ANY crop count (a chunk of 13 654 crops: 57.8 -> 53.5 ms on the headline workload)
@@ -1041,7 +1043,7 @@ int obj_encode(Run& R, const uint8_t* const crops[2], const int64_t* const bbox[
   if (M == 0) return 0;
   // equal-size chunks (crops are independent); with dual_stream an even number of them, alternating between streams
   const int cmax = h->vit_chunk > 0 ? h->vit_chunk : M;
-  const bool dual = h->dual_stream && M >= 512;
+  const bool dual = h->dual_stream && M >= (h->dual_vit_crops > 512 ? h->dual_vit_crops : 512);
   int nchunks = (M + cmax - 1) / cmax;
   if (dual && (nchunks & 1)) ++nchunks;
   if (dual && nchunks < 2) nchunks = 2;
@@ -1302,7 +1304,13 @@ int t5_stack(Run& R, float* x, const uint8_t* mask, int B, int L, float* out32, 
   VimaHandle* h = R.h;
   float* table = nullptr;
   if (int e = t5_bias_table(h, L, &table)) return R.err = e;
-  const bool dual = h->dual_stream && B >= 2;
+  // Two streams (half the batch each) overlap one half's attention with the other's GEMMs and interleave partial rounds of tiles -- except where the whole batch's
+  // N = 768 GEMMs are ONE nearly full round of 256x256 tiles (169 .. 256 of them: 14.4 k .. 21.8 k rows, e.g. batch 32 or 40 x 512 tokens): two half-filled grids side by
+  // side are then slower than the one (batch 32: 9.10 -> 8.78 ms, batch 40: 10.57 -> 10.28; batch 24 / 48 / 64 the other way round: profiles/r06_dual_stream_thresholds.txt).
+  // Option dual_t5_rows > 0 replaces the rule by a plain minimum row count.
+  const long long t5_rows = (long long)B * L, t5_tiles768 = (t5_rows + 255) / 256 * (kT5Model / 256);
+  const bool one_round = h->dual_t5_rows == 0 && t5_tiles768 > 168 && t5_tiles768 <= 256;
+  const bool dual = h->dual_stream && B >= 2 && t5_rows >= h->dual_t5_rows && !one_round;
   const int nb[2] = {dual ? B - B / 2 : B, dual ? B / 2 : 0};
   T5Buf buf[2];
   // option t5_pad: a half whose row count is not a multiple of 256 (the 256x256 tile kernels take nothing else) is computed on the next multiple when it has at
@@ -1697,6 +1705,8 @@ int vima_set_option(VimaHandle* h, const char* key, int64_t value) {
   else if (k == "vit_chunk") h->vit_chunk = (int)value;
   else if (k == "vit_pad") h->vit_pad = (int)value;
   else if (k == "t5_pad") h->t5_pad = (int)value;
+  else if (k == "dual_t5_rows") h->dual_t5_rows = (int)value;
+  else if (k == "dual_vit_crops") h->dual_vit_crops = (int)value;
   else if (k == "vit_prune_last") h->vit_prune_last = (int)value;
   else if (k == "dual_stream") h->dual_stream = (int)value;
   else if (k == "op_bf16_out") h->op_bf16_out = (int)value;
