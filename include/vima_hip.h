@@ -294,7 +294,7 @@ int vima_t5_bucket(int relative_position);
  *   scheduling:              "dual_stream"  [1] independent halves of the work on an auxiliary HIP stream
  *                            "graphs"       [0] replay the per-step entry points as captured hipGraphs
  *                            "vit_chunk"    [16384] crops per ViT pass
- *                            "dual_t5_rows" [0] 0 = automatic (two streams unless the batch is one nearly full round of 256x256 tiles, 14.4 k .. 21.8 k rows), > 0: batch x prompt length from which dual_stream splits the T5 stack over two streams; "dual_vit_crops" [512] the same for the ViT's chunks (crops)
+ *                            "dual_t5_rows" [0] 0 = automatic (two streams unless the batch is one nearly full round of 256x256 tiles, 14.4 k .. 21.8 k rows), > 0: batch x prompt length from which dual_stream splits the T5 stack over two streams; "dual_vit_crops" [8192] the same for the ViT's chunks (crops)
  *                            "t5_pad"       [1] the T5 stack is computed on the next multiple of 256 rows when batch x prompt length (>= 2048 rows per stream) is not one (zero pad rows, never read)
  *                            "vit_pad"      [1] ViT passes of >= 1024 crops are computed on a multiple of 256 crops (zero-image pad crops, never read) so their GEMMs stay on the 256-row tile kernels at any crop count
  *   test / instrumentation:  "op_bf16_out", "op_stream_T" (route vima_op_linear through the bf16-output / bf16-residual

@@ -197,7 +197,9 @@ struct VimaHandle {
   Tuning tune;              // GEMM / attention kernel-selection knobs of THIS handle (travel with every launch)
   int vit_chunk = 16384;
   int dual_t5_rows = 0;                           // option "dual_t5_rows": batch x prompt length from which the T5 stack splits the batch over two streams (with dual_stream)
-  int dual_vit_crops = 512;                       // option "dual_vit_crops": crop count from which the ViT alternates its chunks between two streams (with dual_stream)
+  int dual_vit_crops = 8192;                      // option "dual_vit_crops": crop count from which the ViT alternates its chunks between two streams (with dual_stream). 8192: the 2 048
+                                                  // observation crops of a batch-256 env step as two 1 024-crop chunks on two streams were 4 % SLOWER than one pass (warm step 4.11 -> 3.93 ms,
+                                                  // incremental 4.58 -> 4.44; batch-16 prompts 5.97 -> 5.86); from 16 384 crops on the split pays (profiles/r06_dual_stream_thresholds.txt)
   int t5_pad = 1;                                 // option "t5_pad": the T5 stack's GEMMs run on the next multiple of 256 rows (pad rows: zeros in, never read) when B * L is not one
   int vit_pad = 1;                                // option "vit_pad": ViT chunks of >= 1024 crops run on a multiple of 256 crops (pad crops computed and never read), so that their
                                                  // GEMMs keep the 256x256 kernels at ANY crop count (a chunk of 13 654 crops: 57.8 -> 53.5 ms on the headline workload)
