@@ -250,9 +250,10 @@ int vima_t5_bucket(int relative_position);
  *                            "gemm_persist" [1] large bf16 GEMMs on the persistent 256x256 kernels
  *                            "gemm_pp"      [1] ping-pong (8-phase) main loop of the persistent kernel (0: the round-2 loop)
  *                            "gemm_wide"    [0] 256x384 persistent tile where N % 384 == 0
- *                            "gemm_q4"      [0] gemm_q4_kernel, FOUR waves (one per SIMD) with a 384-column tile, where N % 384 == 0, K % 128 == 0 (bf16-output /
+ *                            "gemm_q4"      [6] gemm_q4_kernel, FOUR waves (one per SIMD) with a 384-column tile, where N % 384 == 0, K % 128 == 0 (bf16-output /
  *                                               bf16-stream / head-major epilogues): 1 its 256x384 tile wherever it fits, 2 its 128x384 tile wherever it fits,
- *                                               3 the 128x384 tile where it needs fewer rounds of the chip than the 256x256 tiling (batch 32), 0 off
+ *                                               3 the 128x384 tile where it needs fewer rounds of the chip than the 256x256 tiling (batch 32), 6 (default) the 256x384 tile
+ *                                               for GEMMs of >= 32 768 rows (wall clock of the two-stream model: -1.4 % on the headline step), 0 off; bit-identical results in every mode
  *                            "gemm_small"   [1] 64x64 / 32x64 tiles for grids that would leave most CUs idle
  *                            "gemm_resident" [1] underfilled grids on gemm_resident_kernel ((almost) the whole K extent in flight, one
  *                                               barrier per chunk of K-slices; bit-identical to the ring tiles), 0: the 4-deep ring tiles

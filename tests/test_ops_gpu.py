@@ -725,6 +725,6 @@ def test_linear_q4_tile_is_bit_identical(M, N, K, act, stream, mode):
         ref = bf(ref + bf(r)) if stream else bf(ref)
         assert max_rel(outs[1], ref) < 6e-3, max_rel(outs[1], ref)
     finally:
-        pol.set_option("gemm_q4", 0)
+        pol.set_option("gemm_q4", 6)   # the default: the 256x384 tile from 32 768 rows on
         pol.set_option("op_bf16_out", 0)
         pol.set_option("op_stream_T", 0)

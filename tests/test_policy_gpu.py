@@ -1025,14 +1025,15 @@ def test_q4_gemm_tile_in_the_headline_batch_is_bit_identical():
         otok, omask = pol.forward_obs_token(obs)
         return ptok, otok, pol.action_logits(pol.forward(otok, omask, None, ptok, pmask)[-1])
 
+    pol.set_option("gemm_q4", 0)            # the 256x256 kernels everywhere
     ref = step()
-    pol.set_option("gemm_q4", 1)
+    pol.set_option("gemm_q4", 1)            # the 256x384 tile wherever it fits (the default, 6, takes it from 32 768 rows on)
     pol.prof_enable(True)
     got = step()
     torch.cuda.synchronize()
     kinds = sorted(set(l["kernel"] for l in pol.prof_read_gemm_launches() if "gemm_q4_kernel" in l["kernel"]))
     pol.prof_enable(False)
-    pol.set_option("gemm_q4", 0)
+    pol.set_option("gemm_q4", 6)
     print(f"[q4] kernels in the headline step: {kinds}")
     assert any(k.endswith("<0, 4, 2>") for k in kinds) and any(k.endswith("<0, 5, 2>") for k in kinds) and any(k.endswith("<0, 1, 2>") for k in kinds) \
         and any(k.endswith("<3, 1, 2>") for k in kinds), kinds

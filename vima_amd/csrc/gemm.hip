@@ -1891,7 +1891,7 @@ VIMA_KNOB(gemm_wide, gemm_wide, "VIMA_GEMM_WIDE", g_env_wide, 0)
 int g_env_pp = -1;
 VIMA_KNOB(gemm_pp, gemm_pp, "VIMA_GEMM_PP", g_env_pp, 1)
 int g_env_q4 = -1;
-VIMA_KNOB(gemm_q4, gemm_q4, "VIMA_GEMM_Q4", g_env_q4, 0)
+VIMA_KNOB(gemm_q4, gemm_q4, "VIMA_GEMM_Q4", g_env_q4, 6)
 int g_env_resident = -1, g_env_res_maxwg = -1;
 VIMA_KNOB(gemm_resident, gemm_resident, "VIMA_GEMM_RESIDENT", g_env_resident, 1)
 VIMA_KNOB(gemm_res_maxwg, gemm_res_maxwg, "VIMA_GEMM_RES_MAXWG", g_env_res_maxwg, 256)
@@ -2532,6 +2532,13 @@ int launch_t(const GemmArgs& a, hipStream_t st) {
       // instead of 24); the margin keeps the choice away from ties. M = 16 384 (batch 32): N = 768 one round instead of one of 192 tiles, N = 1536 / 2304 2 / 3 rounds
       // instead of 2 / 3 larger ones; the batch-256 shapes (M = 131 072, 81 920) never qualify. The choice depends on the SHAPE only, and the tile is bit-identical anyway.
       int mode = gemm_q4(a.tune);
+      // 6 (the default since the end of round 6) = the 256 x 384 tile for GEMMs of at least 32 768 rows. Kernel for kernel the two tilings take the same time
+      // (power-bound: DESIGN.md 4.2c) -- but with the model's TWO streams the four-wave kernel's 7 % fewer busy cycles are left to whatever runs beside it:
+      // wall clock of the headline step 53.63 -> 52.89 ms, 1024-token prompt 109.8 -> 108.2, T = 8 65.6 -> 65.0, batch 128 27.85 -> 27.58 (alternating, same box:
+      // profiles/r06_q4_wall_clock.txt); below that size it loses (batch 32 +5 %, the env steps +1 %, VIMA-20M batch 32 +3 %), hence the row threshold.
+      if (mode == 6) mode = a.M >= 32768 ? 1 : 0;
+      if (mode == 4) mode = a.N >= 1536 ? 1 : 0;   // 4 / 5 (lab): the 256 x 384 tile for the wide-N GEMMs only / for N = 768 only
+      if (mode == 5) mode = a.N == 768 ? 1 : 0;
       if (mode == 3) {
         mode = 0;
         if (a.M % 128 == 0 && a.N % 384 == 0 && a.M % 256 == 0 && a.N % 256 == 0) {

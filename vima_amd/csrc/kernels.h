@@ -17,7 +17,7 @@ struct Tuning {
   int gemm_wide = -1;      // VIMA_GEMM_WIDE     1 = 256x384 persistent tile where N % 384 == 0 (bf16-out / bf16-residual epilogues)
   int gemm_pp = -1;        // VIMA_GEMM_PP       1 = ping-pong (8-phase) main loop on the persistent 256x256 kernel (default), 0 = the round-2 loop
   int gemm_q4 = -1;        // VIMA_GEMM_Q4       four-wave (one wave per SIMD) kernel, N % 384 == 0, K % 128 == 0, bf16-out / bf16-stream / head-major epilogues: 1 = its 256x384 tile wherever it fits,
-                           //                    2 = its 128x384 tile wherever it fits, 3 = the 128x384 tile where it needs fewer rounds of the chip than 256x256 tiles (batch 32), 0 = off
+                           //                    2 = its 128x384 tile wherever it fits, 3 = the 128x384 tile where it needs fewer rounds of the chip than 256x256 tiles (batch 32), 6 = the 256x384 tile from 32 768 rows on (default), 0 = off
   int gemm_splitk = -1;    // VIMA_GEMM_SPLITK   1 = two-pass split-K for underfilled grids with K >= 1536 (default 0)
   int gemm_resident = -1;  // VIMA_GEMM_RESIDENT 1 = underfilled grids on gemm_resident_kernel (whole K in flight; default), 0 = the 4-deep ring tiles
   int gemm_res_maxwg = -1; // VIMA_GEMM_RES_MAXWG largest grid (workgroups) that kernel takes at M > 32 (default 256 = one per CU)
