@@ -14,7 +14,7 @@ import re
 import sqlite3
 import sys
 
-GEMM_MARKERS = ("gemm_kernel<", "gemm_persistent_kernel", "gemm_pp_kernel", "gemm_wide_kernel", "gemm_resident_kernel")
+GEMM_MARKERS = ("gemm_kernel<", "gemm_persistent_kernel", "gemm_pp_kernel", "gemm_wide_kernel", "gemm_q4_kernel", "gemm_resident_kernel")
 
 
 def short(name):
@@ -132,7 +132,7 @@ def write_md(summ, out_md, title=None):
         fh.write("| kernel | launches | avg FETCH_SIZE KiB | avg WRITE_SIZE KiB | corrected MB / launch |\n|---|---|---|---|---|\n")
         for r in summ["_table"][:25]:
             fh.write(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.0f} | {r[4] / 1e6:.1f} |\n")
-        fh.write(f"\nAll bf16 GEMM instantiations (`gemm_kernel<bf16,...>`, `gemm_pp_kernel`, `gemm_persistent_kernel`, `gemm_wide_kernel`): "
+        fh.write(f"\nAll bf16 GEMM instantiations (`gemm_kernel<bf16,...>`, `gemm_pp_kernel`, `gemm_persistent_kernel`, `gemm_wide_kernel`, `gemm_q4_kernel`): "
                  f"{summ['gemm_bf16_launches']} launches, {summ['gemm_bf16_bytes_per_launch'] / 1e6:.1f} MB per launch on average.\n")
         if summ.get("per_shape"):
             fh.write(f"\n## Per GEMM shape ({summ['per_shape_note']})\n\nalgorithmic = each bf16 operand once + output (+ residual / gate read, RMS partials)\n\n")
