@@ -1093,3 +1093,34 @@ def test_t5_padded_rows_are_bit_identical(B, L):
         pol.set_option("dual_stream", 1)
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), max_abs(a, b)
+
+
+@pytest.mark.gpu
+def test_default_tiling_choices_are_bit_identical_at_an_odd_size():
+    """VIMA-200M at batch 50 with 496-token prompts (24 800 T5 rows, 25 600 + 400 crops: nothing a multiple of 256): the defaults -- T5 streams and ViT chunks computed on
+    padded row counts (t5_pad, vit_pad), the 256x384 GEMM tile from 32 768 rows on (gemm_q4 = 6) -- against the plain run without any of them. Every choice only changes WHICH
+    tile kernel multiplies which rows, so the whole policy forward (prompt_encoder.py / vit.py / xattn_gpt.py) must return the same bits."""
+    cfg = syn.config("200M", xattn_n_positions=512)
+    sd = syn.make_state_dict(cfg, 0)
+    pol = loaded_policy(cfg, sd, "bf16")
+    B = 50
+    prompts = syn.to_device(syn.make_prompt(B, n_segments=31, words_per_segment=8, q_per_view=4, seed=1236), DEV)
+    obs = syn.to_device(syn.make_obs(1, B, 4, seed=1336), DEV)
+
+    def step():
+        ptok, pmask = pol.forward_prompt_assembly(prompts)
+        otok, omask = pol.forward_obs_token(obs)
+        return ptok, pol.action_logits(pol.forward(otok, omask, None, ptok, pmask)[-1])
+
+    try:
+        a = [t.clone() for t in step()]
+        for k in ("t5_pad", "vit_pad", "gemm_q4"):
+            pol.set_option(k, 0)
+        b = [t.clone() for t in step()]
+    finally:
+        pol.set_option("t5_pad", 1)
+        pol.set_option("vit_pad", 1)
+        pol.set_option("gemm_q4", 6)
+    assert torch.isfinite(a[1]).all()
+    for x, y, what in zip(a, b, ("prompt tokens", "logits")):
+        assert torch.equal(x, y), (what, max_abs(x, y))
